@@ -1,0 +1,105 @@
+"""Oracle: stochastic-interpolant sampler (test infrastructure; see oracle/__init__.py).
+
+Restates /root/reference/VLA/residual_controller/bridge/bridge_model.py: schedules :59-101,
+`sample` :259-279 (EMA weights, sde_type dispatch) and `sde_vs` :334-387, with the Gaussian
+noise injected (`z[k]` = the reference's k-th `torch.randn_like` draw) instead of RNG-matched.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import torch
+
+T_MIN = 1e-3            # bridge_model.py:45
+GAMMA_INV_MAX = 200.0   # bridge_model.py:46
+
+
+def epsilon(t: torch.Tensor, kind: str) -> torch.Tensor:
+    """bridge_model.py:59-71."""
+    if kind == "t(t-1)":
+        return t * (1 - t)
+    if kind == "1-t":
+        return (1 - t) * 1.0
+    if kind == "1-sqrt(t)":
+        return 1 - torch.sqrt(t)
+    if kind == "1-t^2":
+        return 1 - torch.pow(t, 2)
+    if kind == "0":
+        return t * 0.0
+    raise NotImplementedError(kind)
+
+
+def gamma(t: torch.Tensor, kind: str) -> torch.Tensor:
+    """bridge_model.py:73-81 (note the literal 1.4142)."""
+    if kind == "(2t(t-1))^0.5":
+        return 1.4142 * torch.sqrt(t * (1 - t))
+    if kind == "2^0.5*t(t-1)":
+        return 1.4142 * t * (1 - t)
+    if kind == "(1-t)^2(2t)^0.5":
+        return 1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t)
+    raise NotImplementedError(kind)
+
+
+def gamma_der(t: torch.Tensor, kind: str) -> torch.Tensor:
+    """bridge_model.py:83-91."""
+    if kind == "(2t(t-1))^0.5":
+        return (1 - 2 * t) / torch.sqrt(2 * (t - torch.pow(t, 2)) + 1e-4)
+    if kind == "2^0.5*t(t-1)":
+        return 1.4142 * (1 - 2 * t)
+    if kind == "(1-t)^2(2t)^0.5":
+        return 1.4142 * (2 * (t - 1) * torch.sqrt(t) + torch.pow((1 - t), 2.0) / (2.0 * torch.sqrt(t + 1e-4)))
+    raise NotImplementedError(kind)
+
+
+def gamma_inv(t: torch.Tensor, kind: str) -> torch.Tensor:
+    """bridge_model.py:93-101."""
+    if kind == "(2t(t-1))^0.5":
+        return torch.clamp(1 / (1.4142 * torch.sqrt(t * (1 - t) + 1e-4)), 0.0, GAMMA_INV_MAX)
+    if kind == "2^0.5*t(t-1)":
+        return torch.clamp(1 / (1.4142 * t * (1 - t) + 1e-4), 0.0, GAMMA_INV_MAX)
+    if kind == "(1-t)^2(2t)^0.5":
+        return torch.clamp(1 / (1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t) + 1e-4), 0.0, GAMMA_INV_MAX)
+    raise NotImplementedError(kind)
+
+
+def step_coefficients(k: int, n_steps: int, gamma_type: str, epsilon_type: str):
+    """Per-step scalars of the forward `sde_vs` update (bridge_model.py:346-384) in fp32:
+    returns (t, c_s, noise_scale) with  x <- x + dt*(v + c_s*s) + noise_scale*d*z  where
+    c_s = eps*(1 - gamma*gamma_dot)*gamma_inv  (score_weight = 1)."""
+    t = torch.clip(torch.full((1,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
+    g, gd, gi = gamma(t, gamma_type), gamma_der(t, gamma_type), gamma_inv(t, gamma_type)
+    eps = epsilon(t, epsilon_type)
+    dt = float(1.0 / n_steps)
+    noise_scale = dt * torch.sqrt(2 * eps)
+    return t, g, gd, gi, eps, dt, noise_scale
+
+
+def sde_vs(v_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torch.Tensor,
+           noise: torch.Tensor, diffuse_step: int = 10, beta_max: float = 0.03,
+           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t") -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Forward velocity-score SDE, Euler–Maruyama (bridge_model.py:334-387).
+
+    `v_net(x, t, cond)` / `s_net(x, t, cond)`; `noise[k-1]` is the N(0,1) draw of step k (the
+    reference multiplies it by d = beta_max, :372).  Operation order follows the reference so
+    the fp32 result matches to rounding."""
+    delta_t = float(1.0 / diffuse_step)
+    n_steps = int(1.0 / delta_t)
+    n = x_initial.shape[0]
+    xs = [x_initial]
+    for k in range(1, n_steps + 1):
+        x = xs[-1]
+        t = torch.clip(torch.full((n,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
+        g, gd = gamma(t, gamma_type), gamma_der(t, gamma_type)
+        v = v_net(x, t, cond)
+        s = s_net(x, t, cond)
+        gi = gamma_inv(t, gamma_type)
+        s = s * gi[:, None, None]
+        gdg = (gd * g)[:, None, None]
+        b = v - gdg * s * epsilon(t[0], epsilon_type)
+        dW = beta_max * noise[k - 1]
+        noise_scale = delta_t * torch.sqrt(2 * epsilon(t[0], epsilon_type))
+        score_eps = 1.0 * epsilon(t[0], epsilon_type)
+        new_x = x + (b + score_eps * s) * delta_t
+        new_x = new_x + noise_scale * dW
+        xs.append(new_x)
+    return xs[-1], xs

@@ -1,0 +1,123 @@
+"""CPU: the oracle (oracle/*) against golden vectors captured from the imported reference
+(tools/make_golden.py).  This is what pins the oracle (task ③); tolerance 2e-5 fp32."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from oracle import controller as oc, dinov2 as od, interpolant as oi, normalize as on, rdt as orr, unet1d as ou
+from vlatouch import synth
+
+torch.set_grad_enabled(False)
+G = lambda n: np.load(os.path.join(cases.GOLDEN, n + ".npz"))
+
+
+def close(a, b, tol, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    err = np.abs(a - b).max()
+    assert err <= tol, f"{what}: max abs err {err:.3e} > {tol}"
+
+
+def test_g1_unet_forward():
+    g = G("g1_unet_fwd")
+    sd = cases.si_net_sd()
+    for (B, T) in ((2, 16), (3, 32)):
+        x, cond = cases.unet_inputs(B, T)
+        for tv in (0.1, 0.5, 0.999):
+            t = torch.full((B,), tv)
+            for net in ("v", "s"):
+                y = ou.unet_forward(sd, f"{net}_net.", x, t, cond)
+                close(y, g[f"{net}_B{B}_T{T}_t{tv}"], 2e-5, f"{net} B{B} T{T} t{tv}")
+
+
+@pytest.mark.parametrize("T", [16, 32])
+def test_g2_si_trajectory_uses_ema_weights(T):
+    g = G(f"g2_si_traj_T{T}")
+    sd = cases.si_net_sd("ema")
+    x0, cond, _ = cases.si_inputs(2, T)
+    v = lambda x, t, c: ou.unet_forward(sd, "v_net.", x, t, c)
+    s = lambda x, t, c: ou.unet_forward(sd, "s_net.", x, t, c)
+    xT, traj = oi.sde_vs(v, s, x0, cond, torch.from_numpy(g["z"]))
+    close(torch.stack(traj), g["traj"], 5e-5, "traj")
+    close(xT, g["xT"], 5e-5, "xT")
+
+
+def test_g3_dino_cls():
+    g = G("g3_dino_cls")
+    sd = cases.dino_sd("small")
+    for kind in ("bright", "dark", "uint8_bhwc", "bthwc"):
+        close(od.encode(sd, cases.frames(2, 224, kind), 6), g[f"small_224_{kind}"], 3e-5, kind)
+    close(od.encode(sd, cases.frames(2, 224, "uint8_bhwc").numpy(), 6), g["small_224_numpy_uint8"], 3e-5, "numpy")
+    close(od.encode(sd, cases.frames(1, 384, "bright"), 6), g["small_384_bright"], 3e-5, "384")
+    close(od.encode(sd, cases.frames(1, 518, "bright"), 6), g["small_518_bright"], 3e-5, "518")
+    close(od.encode(cases.dino_sd("base"), cases.frames(2, 224, "bright"), 12), g["base_224_bright"], 3e-5, "base")
+
+
+def test_g5_predict_end_to_end():
+    g = G("g5_predict_e2e")
+    inp = cases.predict_inputs(2, 16, 224)
+    out, traj, cond = oc.predict(cases.dino_sd("small"), 6, cases.state_encoder_sd(781), cases.si_net_sd("ema"),
+                                 cases.stats("nontrivial"), inp["state"], inp["vla"], inp["cam1"], inp["cam2"],
+                                 inp["forces"], torch.from_numpy(g["z"]), record=True)
+    close(cond, g["obs_cond"], 3e-5, "obs_cond")
+    close(out, g["pred"], 1e-4, "pred")
+
+
+def test_g6_lstm():
+    g = G("g6_lstm")
+    mods = cases.lstm_mods(384)
+    st = cases.stats("nontrivial")
+    li = cases.lstm_inputs(2, 16)
+    vn = on.normalize_actions(li["vla"], st, "vla")
+    close(oc.lstm_forward(mods, li["obs_cond"], vn, li["forces"]), g["forward"], 2e-5, "forward")
+    close(oc.lstm_predict_sequence(mods, st, li["obs_cond"], li["vla"], li["forces"]), g["predict_sequence"], 2e-5, "seq")
+    pi = cases.predict_inputs(2, 16, 224)
+    close(oc.lstm_encode_observation(cases.dino_sd("small"), 6, mods["obs_encoder"], pi["state"], pi["cam1"], pi["cam2"]),
+          g["obs_cond"], 3e-5, "obs")
+
+
+def test_g7_normalize():
+    g = G("g7_norm")
+    st = cases.stats("nontrivial")
+    a = cases.predict_inputs(2, 16, 224)["vla"]
+    close(on.normalize_actions(a, st, "vla"), g["n_vla"], 1e-6)
+    close(on.normalize_actions(a, st, "expert"), g["n_exp"], 1e-6)
+    close(on.denormalize_actions(a, st, "vla"), g["d_vla"], 1e-6)
+    close(on.denormalize_actions(a, st, "expert"), g["d_exp"], 1e-6)
+    with pytest.raises(ValueError):
+        on.normalize_actions(a, st, "bogus")
+
+
+@pytest.mark.parametrize("tag,cfg,B,L", [("tiny", cases.RDT_TINY, 2, 12), ("wide", cases.RDT_WIDE, 1, 20)])
+def test_g8_rdt_forward(tag, cfg, B, L):
+    g = G("g8_rdt_fwd")
+    for dt, dname, tol in ((torch.float32, "f32", 5e-5), (torch.bfloat16, "bf16", 6e-2)):
+        sd = cases.rdt_sd(cfg, dt)
+        ri = cases.rdt_inputs(cfg, B, L, dtype=dt)
+        y = orr.rdt_forward(sd, ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"],
+                            heads=cfg["heads"], horizon=cfg["horizon"])
+        close(y.float(), g[f"{tag}_{dname}"], tol, f"{tag} {dname}")
+
+
+def test_shape_tables_match_reference_modules():
+    with open(os.path.join(cases.GOLDEN, "shapes.json")) as f:
+        ref = json.load(f)
+    mine = {k: list(v) for k, v in synth.si_net_shapes(10, 256).items()}
+    assert list(mine.keys()) == list(ref["si_net"].keys()) or sorted(mine.keys()) == sorted(ref["si_net"].keys())
+    assert mine == ref["si_net"]
+    for size in ("small", "base"):
+        c = synth.DINOV2_CONFIGS[size]
+        assert {k: list(v) for k, v in synth.dinov2_shapes(c["hidden"], c["layers"]).items()} == ref[f"dinov2_{size}"]
+    assert {k: list(v) for k, v in synth.state_encoder_shapes(781).items()} == ref["state_encoder"]
+    assert {k: list(v) for k, v in synth.force_decoder_shapes().items()} == ref["force_decoder"]
+    lm = synth.lstm_controller_shapes(384)
+    for m in ("obs_encoder", "force_encoder", "lstm", "output_head"):
+        assert {k: list(v) for k, v in lm[m].items()} == ref[f"lstm_{m}"], m
+    r = ref["rdt_tiny_model"]
+    mine = {k: list(v) for k, v in synth.rdt_runner_shapes(**cases.RDT_TINY).items() if k.startswith("model.")}
+    assert mine == r
+    # EMA shadow list order == net.parameters() order == state-dict order (no buffers in the U-Nets)
+    assert ref["si_param_order"] == list(synth.si_net_shapes(10, 256).keys())

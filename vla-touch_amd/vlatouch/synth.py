@@ -1,0 +1,270 @@
+"""Deterministic synthetic weights and inputs.
+
+There is no network on either box, so no pretrained DINOv2 / RDT / controller
+checkpoint exists.  Every tensor is regenerated from its *state-dict key and
+shape* by a counter-based generator (numpy Philox keyed by a SHA-256 of the
+name), so the golden-vector generator (tools/make_golden.py, which fills the
+imported reference modules), the oracle, the HIP path and bench.py all see
+bit-identical weights without shipping them.
+
+Scales are chosen so activations stay O(1) through deep stacks and so that
+every parameter is non-trivial (norm gains != 1, biases != 0): a kernel that
+drops an affine term fails parity.
+"""
+from __future__ import annotations
+
+import hashlib
+from typing import Dict, Iterable, Mapping, Sequence, Tuple
+
+import numpy as np
+
+__all__ = ["tensor", "fill_state_dict", "inputs_rng", "unet_shapes", "si_net_shapes",
+           "dinov2_shapes", "DINOV2_CONFIGS", "state_encoder_shapes", "lstm_controller_shapes",
+           "rdt_runner_shapes"]
+
+
+def _rng(name: str, salt: str = "") -> np.random.Generator:
+    h = hashlib.sha256((salt + "|" + name).encode()).digest()
+    key = np.frombuffer(h[:16], dtype=np.uint64)
+    return np.random.Generator(np.random.Philox(key=key))
+
+
+def tensor(name: str, shape: Sequence[int], salt: str = "") -> np.ndarray:
+    """fp32 tensor for state-dict key `name` with `shape` (rule depends on name+shape only)."""
+    shape = tuple(int(s) for s in shape)
+    g = _rng(name, salt)
+    z = g.standard_normal(size=shape, dtype=np.float32)
+    leaf = name.split(".")[-1]
+    if any(k in name for k in ("pos_embed", "position_embeddings", "cls_token", "mask_token")):
+        return (0.2 * z).astype(np.float32)
+    if len(shape) >= 2:
+        fan_in = int(np.prod(shape[1:]))
+        return (z / np.sqrt(max(fan_in, 1))).astype(np.float32)
+    # 1-D tensors: norm gains / LayerScale vs biases
+    if leaf in ("weight", "lambda1"):
+        return (1.0 + 0.1 * z).astype(np.float32)
+    return (0.1 * z).astype(np.float32)
+
+
+def fill_state_dict(shapes: Mapping[str, Sequence[int]], prefix: str = "", salt: str = "") -> Dict[str, np.ndarray]:
+    return {k: tensor(prefix + k, s, salt) for k, s in shapes.items()}
+
+
+def inputs_rng(seed: int = 1234) -> np.random.Generator:
+    """synthetic inputs come from numpy PCG64(seed)."""
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# --------------------------------------------------------------------------------------
+# Shape tables (the checkpoint key maps of SURVEY Appendix A).  These are the build's own
+# statement of the boundary; tests/test_shapes_vs_reference.py checks them against the
+# key/shape lists captured from the imported reference modules (tests/golden/shapes.json).
+# --------------------------------------------------------------------------------------
+
+def _resblock(p: str, cin: int, cout: int, cond: int, k: int) -> Dict[str, Tuple[int, ...]]:
+    d = {
+        f"{p}.blocks.0.block.0.weight": (cout, cin, k), f"{p}.blocks.0.block.0.bias": (cout,),
+        f"{p}.blocks.0.block.1.weight": (cout,), f"{p}.blocks.0.block.1.bias": (cout,),
+        f"{p}.blocks.1.block.0.weight": (cout, cout, k), f"{p}.blocks.1.block.0.bias": (cout,),
+        f"{p}.blocks.1.block.1.weight": (cout,), f"{p}.blocks.1.block.1.bias": (cout,),
+        f"{p}.cond_encoder.1.weight": (2 * cout, cond), f"{p}.cond_encoder.1.bias": (2 * cout,),
+    }
+    if cin != cout:
+        d[f"{p}.residual_conv.weight"] = (cout, cin, 1)
+        d[f"{p}.residual_conv.bias"] = (cout,)
+    return d
+
+
+def unet_shapes(input_dim: int = 10, global_cond_dim: int = 256, dsed: int = 256,
+                down_dims: Sequence[int] = (256, 512, 512), k: int = 5) -> Dict[str, Tuple[int, ...]]:
+    """Key/shape map of one conditional 1-D U-Net (reference conditional_unet_1D.py:108-192);
+    registration order mid, step-encoder, up, down, final (conditional_unet_1D.py:143,185-188)."""
+    cond = dsed + global_cond_dim
+    all_dims = [input_dim] + list(down_dims)
+    in_out = list(zip(all_dims[:-1], all_dims[1:]))
+    mid = all_dims[-1]
+    d: Dict[str, Tuple[int, ...]] = {}
+    for i in range(2):
+        d.update(_resblock(f"mid_modules.{i}", mid, mid, cond, k))
+    d["diffusion_step_encoder.1.weight"] = (dsed * 4, dsed)
+    d["diffusion_step_encoder.1.bias"] = (dsed * 4,)
+    d["diffusion_step_encoder.3.weight"] = (dsed, dsed * 4)
+    d["diffusion_step_encoder.3.bias"] = (dsed,)
+    for ind, (din, dout) in enumerate(reversed(in_out[1:])):
+        d.update(_resblock(f"up_modules.{ind}.0", dout * 2, din, cond, k))
+        d.update(_resblock(f"up_modules.{ind}.1", din, din, cond, k))
+        # `is_last` in the reference is never true in the up path (ind >= len(in_out)-1 with
+        # ind < len(in_out)-1), so every level has a ConvTranspose1d(k=4) (weight is (in,out,k)).
+        d[f"up_modules.{ind}.2.conv.weight"] = (din, din, 4)
+        d[f"up_modules.{ind}.2.conv.bias"] = (din,)
+    for ind, (din, dout) in enumerate(in_out):
+        d.update(_resblock(f"down_modules.{ind}.0", din, dout, cond, k))
+        d.update(_resblock(f"down_modules.{ind}.1", dout, dout, cond, k))
+        if ind < len(in_out) - 1:
+            d[f"down_modules.{ind}.2.conv.weight"] = (dout, dout, 3)
+            d[f"down_modules.{ind}.2.conv.bias"] = (dout,)
+    s = down_dims[0]
+    d["final_conv.0.block.0.weight"] = (s, s, k)
+    d["final_conv.0.block.0.bias"] = (s,)
+    d["final_conv.0.block.1.weight"] = (s,)
+    d["final_conv.0.block.1.bias"] = (s,)
+    d["final_conv.1.weight"] = (input_dim, s, 1)
+    d["final_conv.1.bias"] = (input_dim,)
+    return d
+
+
+def si_net_shapes(input_dim: int = 10, global_cond_dim: int = 256, **kw) -> Dict[str, Tuple[int, ...]]:
+    """b_net, v_net, s_net in registration order (conditional_unet_1D_si.py:25-50)."""
+    one = unet_shapes(input_dim, global_cond_dim, **kw)
+    d: Dict[str, Tuple[int, ...]] = {}
+    for net in ("b_net", "v_net", "s_net"):
+        for kname, shp in one.items():
+            d[f"{net}.{kname}"] = shp
+    return d
+
+
+DINOV2_CONFIGS = {
+    # name fragment -> (hidden, layers, heads)  (visual_encoder.py:31-46; HF configs)
+    "small": dict(hidden=384, layers=12, heads=6),
+    "base": dict(hidden=768, layers=12, heads=12),
+    "large": dict(hidden=1024, layers=24, heads=16),
+}
+
+
+def dinov2_shapes(hidden: int, layers: int, heads: int = 0, image_size: int = 518, patch: int = 14) -> Dict[str, Tuple[int, ...]]:
+    """HF Dinov2Model key map."""
+    n_pos = (image_size // patch) ** 2 + 1
+    D = hidden
+    d: Dict[str, Tuple[int, ...]] = {
+        "embeddings.cls_token": (1, 1, D),
+        "embeddings.mask_token": (1, D),
+        "embeddings.position_embeddings": (1, n_pos, D),
+        "embeddings.patch_embeddings.projection.weight": (D, 3, patch, patch),
+        "embeddings.patch_embeddings.projection.bias": (D,),
+    }
+    for i in range(layers):
+        p = f"encoder.layer.{i}"
+        d[f"{p}.norm1.weight"] = (D,)
+        d[f"{p}.norm1.bias"] = (D,)
+        for n in ("query", "key", "value"):
+            d[f"{p}.attention.attention.{n}.weight"] = (D, D)
+            d[f"{p}.attention.attention.{n}.bias"] = (D,)
+        d[f"{p}.attention.output.dense.weight"] = (D, D)
+        d[f"{p}.attention.output.dense.bias"] = (D,)
+        d[f"{p}.layer_scale1.lambda1"] = (D,)
+        d[f"{p}.norm2.weight"] = (D,)
+        d[f"{p}.norm2.bias"] = (D,)
+        d[f"{p}.mlp.fc1.weight"] = (4 * D, D)
+        d[f"{p}.mlp.fc1.bias"] = (4 * D,)
+        d[f"{p}.mlp.fc2.weight"] = (D, 4 * D)
+        d[f"{p}.mlp.fc2.bias"] = (D,)
+        d[f"{p}.layer_scale2.lambda1"] = (D,)
+    d["layernorm.weight"] = (D,)
+    d["layernorm.bias"] = (D,)
+    return d
+
+
+def _mlp3(din: int, h: int, dout: int) -> Dict[str, Tuple[int, ...]]:
+    return {"0.weight": (h, din), "0.bias": (h,), "2.weight": (h, h), "2.bias": (h,),
+            "4.weight": (dout, h), "4.bias": (dout,)}
+
+
+def state_encoder_shapes(obs_dim: int, hidden: int = 256) -> Dict[str, Tuple[int, ...]]:
+    """bridge_controller.py:42-48 (Linear-GELU-Linear-GELU-Linear)."""
+    return _mlp3(obs_dim, hidden, hidden)
+
+
+def force_decoder_shapes(hidden: int = 256, force_dim: int = 3) -> Dict[str, Tuple[int, ...]]:
+    """bridge_controller.py:50-56 (loaded, unused at inference)."""
+    return {"0.weight": (hidden, hidden), "0.bias": (hidden,), "2.weight": (hidden // 2, hidden),
+            "2.bias": (hidden // 2,), "4.weight": (force_dim, hidden // 2), "4.bias": (force_dim,)}
+
+
+def lstm_controller_shapes(latent: int, state_dim: int = 10, hidden: int = 256, layers: int = 2,
+                           force_dim: int = 3) -> Dict[str, Dict[str, Tuple[int, ...]]]:
+    """tactile_controller.pt['modules'] key map (lstm_step_controller.py:44-82)."""
+    obs_dim = 2 * latent + state_dim
+    lstm_in = hidden // 2 + state_dim
+    lstm: Dict[str, Tuple[int, ...]] = {}
+    for l in range(layers):
+        i = lstm_in if l == 0 else hidden
+        lstm[f"weight_ih_l{l}"] = (4 * hidden, i)
+        lstm[f"weight_hh_l{l}"] = (4 * hidden, hidden)
+        lstm[f"bias_ih_l{l}"] = (4 * hidden,)
+        lstm[f"bias_hh_l{l}"] = (4 * hidden,)
+    return {
+        "obs_encoder": _mlp3(obs_dim, hidden, hidden),
+        "force_encoder": {"0.weight": (hidden // 2, force_dim), "0.bias": (hidden // 2,),
+                          "2.weight": (hidden // 2, hidden // 2), "2.bias": (hidden // 2,)},
+        "lstm": lstm,
+        "output_head": {"0.weight": (hidden, 2 * hidden), "0.bias": (hidden,),
+                        "1.weight": (hidden,), "1.bias": (hidden,),
+                        "4.weight": (state_dim, hidden), "4.bias": (state_dim,)},
+    }
+
+
+def _adaptor_shapes(prefix: str, kind: str, din: int, dout: int) -> Dict[str, Tuple[int, ...]]:
+    import re
+    if kind == "linear":
+        return {f"{prefix}.weight": (dout, din), f"{prefix}.bias": (dout,)}
+    m = re.match(r"^mlp(\d+)x_gelu$", kind)
+    if not m:
+        raise ValueError(f"Unknown projector type: {kind}")
+    depth = int(m.group(1))
+    d = {f"{prefix}.0.weight": (dout, din), f"{prefix}.0.bias": (dout,)}
+    for i in range(1, depth):
+        d[f"{prefix}.{2 * i}.weight"] = (dout, dout)
+        d[f"{prefix}.{2 * i}.bias"] = (dout,)
+    return d
+
+
+def rdt_runner_shapes(*, hidden: int, depth: int, heads: int, horizon: int, action_dim: int,
+                      lang_token_dim: int, img_token_dim: int, state_token_dim: int,
+                      max_lang_cond_len: int, img_cond_len: int,
+                      lang_adaptor: str = "mlp2x_gelu", img_adaptor: str = "mlp2x_gelu",
+                      state_adaptor: str = "mlp3x_gelu") -> Dict[str, Tuple[int, ...]]:
+    """RDTRunner state-dict key map (models/rdt/model.py:48-64, blocks.py:33-37,
+    91-97,149-165,192-197; rdt_runner.py:41-60)."""
+    D, hd = hidden, hidden // heads
+    d: Dict[str, Tuple[int, ...]] = {
+        "model.x_pos_embed": (1, horizon + 3, D),
+        "model.lang_cond_pos_embed": (1, max_lang_cond_len, D),
+        "model.img_cond_pos_embed": (1, img_cond_len, D),
+    }
+    for e in ("t_embedder", "freq_embedder"):
+        d[f"model.{e}.mlp.0.weight"] = (D, 256)
+        d[f"model.{e}.mlp.0.bias"] = (D,)
+        d[f"model.{e}.mlp.2.weight"] = (D, D)
+        d[f"model.{e}.mlp.2.bias"] = (D,)
+    for i in range(depth):
+        p = f"model.blocks.{i}"
+        d[f"{p}.norm1.weight"] = (D,)
+        d[f"{p}.attn.qkv.weight"] = (3 * D, D)
+        d[f"{p}.attn.qkv.bias"] = (3 * D,)
+        d[f"{p}.attn.q_norm.weight"] = (hd,)
+        d[f"{p}.attn.k_norm.weight"] = (hd,)
+        d[f"{p}.attn.proj.weight"] = (D, D)
+        d[f"{p}.attn.proj.bias"] = (D,)
+        d[f"{p}.cross_attn.q.weight"] = (D, D)
+        d[f"{p}.cross_attn.q.bias"] = (D,)
+        d[f"{p}.cross_attn.kv.weight"] = (2 * D, D)
+        d[f"{p}.cross_attn.kv.bias"] = (2 * D,)
+        d[f"{p}.cross_attn.q_norm.weight"] = (hd,)
+        d[f"{p}.cross_attn.k_norm.weight"] = (hd,)
+        d[f"{p}.cross_attn.proj.weight"] = (D, D)
+        d[f"{p}.cross_attn.proj.bias"] = (D,)
+        d[f"{p}.norm2.weight"] = (D,)
+        d[f"{p}.ffn.fc1.weight"] = (D, D)
+        d[f"{p}.ffn.fc1.bias"] = (D,)
+        d[f"{p}.ffn.fc2.weight"] = (D, D)
+        d[f"{p}.ffn.fc2.bias"] = (D,)
+        d[f"{p}.norm3.weight"] = (D,)
+    d["model.final_layer.norm_final.weight"] = (D,)
+    d["model.final_layer.ffn_final.fc1.weight"] = (D, D)
+    d["model.final_layer.ffn_final.fc1.bias"] = (D,)
+    d["model.final_layer.ffn_final.fc2.weight"] = (action_dim, D)
+    d["model.final_layer.ffn_final.fc2.bias"] = (action_dim,)
+    d.update(_adaptor_shapes("lang_adaptor", lang_adaptor, lang_token_dim, D))
+    d.update(_adaptor_shapes("img_adaptor", img_adaptor, img_token_dim, D))
+    d.update(_adaptor_shapes("state_adaptor", state_adaptor, state_token_dim * 2, D))
+    return d
