@@ -1,0 +1,216 @@
+#!/usr/bin/env python
+"""bench.py — refined action chunks / s on MI355X for the VLA-Touch action-refinement path.
+
+    python bench.py [--gpus N --steps K --warmup W]            (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one `DiffusionController.predict` over a batch of `--batch` (32) episodes per GPU: 2 camera batches of
+synthetic 224x224 frames -> DINOv2 CLS x2 -> state/force MLP -> 10-step velocity-score SDE over v_net/s_net ->
+denormalised refined chunks [B, T, 10].  Inputs are resident in HBM before the timed region; the sampler's Gaussian
+noise is drawn on device inside the step (as the reference does).  Episodes are independent: ranks take disjoint
+batches (weak scaling), frozen weights are broadcast once from rank 0 over RCCL, no collective in the step loop.
+
+Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` (dominant kernel = the 128x128-tile bf16
+MFMA GEMM, timed live with HIP events on its launch stream) and `cpu_baseline` (the oracle on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "vla-touch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="episodes per GPU per step")
+    ap.add_argument("--horizon", type=int, default=16)
+    ap.add_argument("--res", type=int, default=224)
+    ap.add_argument("--dino", default="base", choices=["small", "base"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--workload", default="pi_refine", choices=["pi_refine", "dino_mlp"],
+                    help="pi_refine: BASELINE configs[3] without the RDT chunk generator (DINOv2 x2 + MLP + interpolant sampler); "
+                         "dino_mlp: configs[1]")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    return ap.parse_args()
+
+
+def synth_inputs(B, T, res, seed, device):
+    """frames 0.2+0.8*U(0,1) (batch mean ~0.6 -> the reference's normalise branch), state/force N(0,1),
+    vla U(0,1), unit stats."""
+    from vlatouch import synth
+    g = synth.inputs_rng(seed)
+    mk = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return dict(
+        cam1=mk((0.2 + 0.8 * g.random((B, 3, res, res), dtype=np.float32))),
+        cam2=mk((0.2 + 0.8 * g.random((B, 3, res, res), dtype=np.float32))),
+        state=mk(g.standard_normal((B, 10), dtype=np.float32)),
+        forces=mk(g.standard_normal((B, 3), dtype=np.float32)),
+        vla=mk(g.uniform(0, 1, (B, T, 10)).astype(np.float32)),
+    )
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path in the product)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    torch.set_grad_enabled(False)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from tests import cases
+    from vlatouch import _lib as L
+    from residual_controller.bridge_controller import DiffusionController
+
+    # ---- frozen weights: rank 0 generates the deterministic synthetic set, the others receive it over RCCL
+    t0 = time.time()
+    ctrl = cases.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats_kind="unit")
+    if world > 1:
+        from vlatouch.dist import broadcast_controller_weights
+        nbytes = broadcast_controller_weights(ctrl, src=0)
+    setup_s = time.time() - t0
+    B, T = args.batch, args.horizon
+    inp = synth_inputs(B, T, args.res, 1234 + rank, dev)
+    noise_buf = torch.empty(10, B, T, 10, dtype=torch.float32, device=dev)
+    out_holder = {}
+
+    def step():
+        if args.workload == "dino_mlp":
+            out_holder["out"] = ctrl.encode_observation(inp["state"], inp["cam1"], inp["cam2"], inp["forces"])
+        else:
+            noise_buf.normal_()          # the reference's torch.randn_like draws (bridge_model.py:372), on device
+            out_holder["out"] = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"], noise=noise_buf)
+
+    stream = torch.cuda.Stream(device=dev)
+    graph = None
+    with torch.cuda.stream(stream):
+        for _ in range(max(1, args.warmup)):       # warm-up also sizes every workspace (no allocation inside the graph)
+            step()
+        stream.synchronize()
+        if not args.no_graph:
+            try:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph, stream=stream):
+                    step()
+                graph.replay()
+                stream.synchronize()
+            except Exception as e:          # pragma: no cover
+                if rank == 0:
+                    print(f"[bench] hipGraph capture failed ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+                graph = None
+        run = (graph.replay if graph is not None else step)
+
+        def barrier():
+            torch.cuda.synchronize(dev)
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        # ---- timed region: exactly K steps, barrier + synchronize on both sides
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        barrier()
+        t_start = time.perf_counter()
+        evs[0].record(stream)
+        for i in range(args.steps):
+            run()
+            evs[i + 1].record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t_start
+        lat = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps))
+        p50 = lat[len(lat) // 2]
+
+        # ---- roofline leg: one eager step with HIP events around every launch of the dominant GEMM kernel
+        lib = L.lib()
+        lib.vt_prof_enable(1)
+        step()
+        stream.synchronize()
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
+        L.check(lib.vt_prof_collect(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "vt_prof_collect")
+        lib.vt_prof_enable(0)
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    total_chunks = B * world * args.steps
+    value = total_chunks / elapsed
+
+    res = {
+        "metric": "refined action chunks/sec" if args.workload == "pi_refine" else "encoded observations/sec",
+        "value": round(value, 2), "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000 * elapsed / args.steps, 4), "p50_step_latency_ms": round(p50, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "config": {
+            "workload": ("pi_refine: 2x DINOv2-%s CLS @%d + state/force MLP + 10-step interpolant SDE (v_net+s_net), T=%d; "
+                         "BASELINE configs[3] WITHOUT the RDT-1B chunk generator (not built yet)" % (args.dino, args.res, T))
+            if args.workload == "pi_refine" else "dino_mlp: BASELINE configs[1] (2x DINOv2-%s @%d + MLP)" % (args.dino, args.res),
+            "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "parallelism": f"dp{world} (episodes sharded, no step collectives)",
+            "hipgraph": graph is not None, "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
+            "weights": "deterministic synthetic (no checkpoints offline)", "setup_s": round(setup_s, 1),
+        },
+    }
+    if n.value > 0 and ms.value > 0:
+        tf = fl.value / (ms.value * 1e-3) / 1e12
+        res["roofline"] = {
+            "kernel": "gemm_kernel<bf16,bf16,*,2,2,4,4> (128x128x64 tile, DINOv2 qkv/proj/fc1/fc2/patch-embed)",
+            "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "launches_per_step": n.value, "avg_launch_us": round(1000 * ms.value / n.value, 2),
+            "algorithmic_gflop_per_step": round(fl.value / 1e9, 1), "algorithmic_gbytes_per_step": round(by.value / 1e9, 3),
+            "share_of_step_time": round(ms.value / (1000 * elapsed / args.steps), 3), "traffic": None,
+        }
+
+    # ---- CPU baseline: the oracle (fp32 torch on the host cores), rank 0, N=1 only, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "pi_refine":
+        from oracle import controller as oc
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cpu = {k: v.cpu() for k, v in inp.items()}
+        z = torch.randn(10, B, T, 10)
+        sds = (cases.dino_sd(args.dino), cases.state_encoder_sd(2 * (768 if args.dino == "base" else 384) + 13), cases.si_net_sd("ema"),
+               cases.stats("unit"))
+        heads = 12 if args.dino == "base" else 6
+        f = lambda: oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"], cpu["vla"], cpu["cam1"], cpu["cam2"], cpu["forces"], z)
+        ref = f()                                   # warm-up + parity of the benchmarked configuration
+        ts = []
+        for _ in range(args.cpu_iters):
+            t1 = time.perf_counter(); f(); ts.append(time.perf_counter() - t1)
+        got = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"], noise=z.to(dev)).cpu()
+        res["cpu_baseline"] = {"value": round(B / float(np.median(ts)), 2), "unit": "chunks/s", "cores": cores, "kind": "port",
+                               "sample": f"{args.cpu_iters} predict() calls of the same B={B} batch (oracle, fp32 torch CPU ops), p50",
+                               "max_abs_diff_vs_gpu": float((got - ref).abs().max())}
+    if rank == 0:
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

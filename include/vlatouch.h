@@ -1,0 +1,151 @@
+/* vlatouch.h — C ABI of libvlatouch_hip.so, the MI355X (gfx950) engine behind the VLA-Touch
+ * action-refinement path.
+ *
+ * The reference (jxbi1010/VLA-Touch) has no FFI: its boundary for this path is the Python class
+ * surface of VLA/residual_controller/ and VLA/models/ (SURVEY.md §8b).  Those classes are mirrored in
+ * vla-touch_amd/{residual_controller,models}/ and bind to the entry points below through ctypes
+ * (vla-touch_amd/vlatouch/_lib.py).  Each entry cites the reference interface it replaces.
+ *
+ * Conventions: every pointer is a DEVICE pointer owned by the caller (PyTorch allocations) unless
+ * marked "host"; no entry allocates device memory, synchronises the device or touches the default
+ * stream — all work is enqueued on `stream` (a hipStream_t).  Return value: 0 on success, negative
+ * errno-style code otherwise (-22 bad argument, -95 unsupported, -5 launch failure);
+ * vt_last_error() returns a host string for the last failure on the calling thread.
+ * dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit).  "cdt" = compute/storage dtype of weights,
+ * "adt" = dtype of activations between kernels.
+ */
+#ifndef VLATOUCH_H
+#define VLATOUCH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* vt_stream_t;   /* hipStream_t */
+typedef struct vt_unet_s* vt_unet_t;
+typedef struct vt_dino_s* vt_dino_t;
+typedef struct vt_lstm_s* vt_lstm_t;
+typedef struct vt_rdt_s* vt_rdt_t;
+
+const char* vt_last_error(void);
+int vt_version(void);
+/* MFMA fragment-layout self test (A = I with asymmetric B, both dtypes); out_err[2] device floats. */
+int vt_selftest_mfma(float* out_err, vt_stream_t stream);
+
+/* Live timing of the dominant kernel class (the 128x128-tile bf16 MFMA GEMM): while enabled, every launch of that
+ * kernel is bracketed by HIP events on its launch stream.  vt_prof_collect (after the caller synchronised the
+ * stream) returns the summed duration, the algorithmic FLOPs / bytes of those launches and their count. */
+int vt_prof_enable(int on);
+int vt_prof_collect(double* total_ms, double* flops, double* bytes, long* launches);
+
+/* ---------------------------------------------------------------- primitives (unit-test hooks) */
+/* Generic GEMM / implicit conv1d: params = struct VtGemmParams (csrc/vt_gemm.h), host pointer.
+ * Replaces torch nn.Linear / nn.Conv1d / nn.ConvTranspose1d calls of
+ * bridge/networks/conditional_unet_1D.py:25,34,49,83, bridge_controller.py:42-48, HF Dinov2 linears. */
+int vt_gemm(const void* params, vt_stream_t stream);
+/* Flash attention, head_dim 64: params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
+ * Replaces F.scaled_dot_product_attention (models/rdt/blocks.py:116-123) and HF Dinov2SelfAttention. */
+int vt_attention(const void* params, vt_stream_t stream);
+/* GroupNorm(+Mish, FiLM, residual) over fp32 split-K slabs: params = struct VtGnParams. */
+int vt_groupnorm(const void* params, vt_stream_t stream);
+/* Row norm: mode 0 LayerNorm, 1 RMSNorm(mean-square), 2 RMSNorm(timm<=1.0.8 unbiased-variance form). */
+int vt_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b,
+               int rows, int D, float eps, int mode, vt_stream_t stream);
+/* controller_dataset.py:303-346 / :349-384 (padding factor 1.4): out = (de)normalise(in) per last-dim stats. */
+int vt_action_normalize(const float* in, float* out, const float* mins, const float* maxs, long n, int dim,
+                        float padding_factor, int denormalize, vt_stream_t stream);
+
+/* ---------------------------------------------------------------- interpolant U-Nets + SDE sampler
+ * Replaces InterpolantsConditionalUnet1D / DiffusionConditionalUnet1D.forward
+ * (bridge/networks/conditional_unet_1D_si.py:4-50, conditional_unet_1D.py:194-247) and
+ * StochasticInterpolants.sample / sde_vs (bridge/bridge_model.py:259-279, 334-387).
+ * A handle evaluates `nets` (1 or 2) structurally identical U-Nets on the same input in grouped launches
+ * (the sampler uses 2 = {v_net, s_net}); weights are packed [nets][...] per layer by the caller in the
+ * order documented in csrc/vt_unet.hip (`vt_unet_weight_order`). */
+typedef struct {
+  int nets;            /* 1 or 2 */
+  int input_dim;       /* 10 */
+  int input_pad;       /* input_dim rounded up to 16 */
+  int cond_dim;        /* global_cond_dim (256) */
+  int dsed;            /* diffusion_step_embed_dim (256) */
+  int n_groups;        /* 8 */
+  int ksize;           /* 5 */
+  int n_levels;        /* 3 */
+  int dims[4];         /* down_dims */
+  int cdt;             /* weight dtype */
+  int adt;             /* activation dtype */
+} vt_unet_desc;
+int vt_unet_create(const vt_unet_desc* desc, const void* const* weights, int n_weights, vt_unet_t* out);
+void vt_unet_destroy(vt_unet_t h);
+int vt_unet_num_weights(const vt_unet_desc* desc);
+size_t vt_unet_workspace_bytes(vt_unet_t h, int B, int T);
+/* out[nets][B][T][input_dim] fp32 = net_i(x, t, cond); t = per-sample timesteps t_dev[B] (device) or, if
+ * t_dev == NULL, the scalar t_host for every sample. */
+int vt_unet_forward(vt_unet_t h, const float* x, const float* t_dev, float t_host, const float* cond,
+                    float* out, int B, int T, void* workspace, vt_stream_t stream);
+/* Forward velocity-score SDE (sde_vs, direction='forward', score_weight 1): x[B][T][dim] fp32 is updated in
+ * place through n_steps Euler–Maruyama steps; noise = N(0,1) draws [n_steps][B][T][dim] (the reference's
+ * torch.randn_like sequence) or NULL for the deterministic drift; traj (optional) receives the n_steps+1
+ * states.  Schedules are the reference's string-keyed ones (bridge_model.py:59-101):
+ *   gamma_type   0 '2^0.5*t(t-1)'   1 '(2t(t-1))^0.5'   2 '(1-t)^2(2t)^0.5'
+ *   epsilon_type 0 '1-t'   1 't(t-1)'   2 '1-sqrt(t)'   3 '1-t^2'   4 '0'
+ *   sde_type     0 'vs' (nets = {v_net, s_net}, sde_vs :334-387)   1 'bs' (nets = {b_net, s_net}, sde_bs :281-332) */
+int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max,
+                 int gamma_type, int epsilon_type, int sde_type, float* traj, int B, int T, void* workspace,
+                 vt_stream_t stream);
+/* In-place per-head RMSNorm over 64-wide head slices (timm Attention q_norm/k_norm, models/rdt/blocks.py:150-156):
+ * x[token*tok_stride + head*64 + 0..63], mode as vt_rownorm (1 or 2). */
+int vt_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode,
+                vt_stream_t stream);
+
+/* ---------------------------------------------------------------- DINOv2 CLS encoder
+ * Replaces DINOv2Encoder.forward/_normalize_images (residual_controller/visual_encoder.py:56-106) and the
+ * HF Dinov2Model forward it calls.  `ncams` image batches (each B images) are preprocessed with their OWN
+ * max()/mean() decisions (one reference call per camera, bridge_controller.py:106-107) and then run through
+ * the transformer as one batch of ncams*B. */
+typedef struct {
+  int hidden, layers, heads, patch, kpad;   /* kpad = 3*patch*patch rounded up to 16 (592) */
+  int cdt, adt;
+  float eps;
+} vt_dino_desc;
+int vt_dino_create(const vt_dino_desc* desc, const void* const* weights, int n_weights, vt_dino_t* out);
+void vt_dino_destroy(vt_dino_t h);
+int vt_dino_num_weights(const vt_dino_desc* desc);
+size_t vt_dino_workspace_bytes(vt_dino_t h, int B_total, int res);
+/* imgs[ncams] device pointers; is_u8: uint8 pixels else fp32; nhwc: [B,H,W,3] else [B,3,H,W];
+ * pre_scale: 1/255 when the caller passed a numpy array (visual_encoder.py:66) else 1;
+ * norm_mode: 0 auto (reference behaviour), 1 force ImageNet-normalise, 2 never;
+ * pos_patch: [grid*grid][hidden] fp32 position embeddings already interpolated for `res`;
+ * out: [ncams][B][hidden] fp32 pooler_output; flags_out (optional) [ncams][4] = {scale, normalised, max, mean}. */
+int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, int nhwc, float pre_scale,
+                    int norm_mode, int B, int res, const float* pos_patch, float* out, float* flags_out,
+                    void* workspace, vt_stream_t stream);
+
+/* ---------------------------------------------------------------- small MLP chain (state encoder / force encoder / heads)
+ * y = L_n(...act(L_1(x))): replaces the nn.Sequential MLPs of bridge_controller.py:42-48 and
+ * lstm_step_controller.py:44-60.  W_i [out_i][in_pad_i] cdt (in padded to 16), b_i fp32.  x is [B][ldx] of adt
+ * with zero padding up to in_pad_1.  tmp: 2*B*max(out_i) adt elements. */
+int vt_mlp(const void* x, long ldx, int B, int n_layers, const int* dims /* n_layers+1, padded ins */,
+           const void* const* W, const float* const* b, int act, void* y, int ydt, long ldy,
+           int cdt, int adt, void* tmp, vt_stream_t stream);
+/* Gather [cls_cam1 | cls_cam2 | state | forces] rows into a zero-padded adt matrix (bridge_controller.py:129-132). */
+int vt_concat_obs(const float* cls1, const float* cls2, int dv, const float* state, int sdim, const float* forces,
+                  int fdim, void* out, int odt, long ldo, int B, vt_stream_t stream);
+
+/* ---------------------------------------------------------------- LSTM residual head
+ * Replaces TactileLSTMController.predict (lstm_step_controller.py:232-286), one control tick:
+ * force MLP -> 2-layer LSTM cell with carried (h, c) -> head -> vla_n + delta -> denormalise('expert'). */
+typedef struct { int state_dim, hidden, layers, force_dim, force_pad, in_pad, cdt; } vt_lstm_desc;
+int vt_lstm_create(const vt_lstm_desc* desc, const void* const* weights, int n_weights, vt_lstm_t* out);
+void vt_lstm_destroy(vt_lstm_t h);
+int vt_lstm_num_weights(const vt_lstm_desc* desc);
+size_t vt_lstm_workspace_bytes(vt_lstm_t h, int B);
+/* out_n[B][state_dim] = vla_n + delta (normalised); h, c: [layers][B][hidden] fp32, updated in place. */
+int vt_lstm_step(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c,
+                 float* out_n, int B, void* workspace, vt_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

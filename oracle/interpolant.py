@@ -62,16 +62,24 @@ def gamma_inv(t: torch.Tensor, kind: str) -> torch.Tensor:
     raise NotImplementedError(kind)
 
 
-def step_coefficients(k: int, n_steps: int, gamma_type: str, epsilon_type: str):
-    """Per-step scalars of the forward `sde_vs` update (bridge_model.py:346-384) in fp32:
-    returns (t, c_s, noise_scale) with  x <- x + dt*(v + c_s*s) + noise_scale*d*z  where
-    c_s = eps*(1 - gamma*gamma_dot)*gamma_inv  (score_weight = 1)."""
-    t = torch.clip(torch.full((1,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
-    g, gd, gi = gamma(t, gamma_type), gamma_der(t, gamma_type), gamma_inv(t, gamma_type)
-    eps = epsilon(t, epsilon_type)
-    dt = float(1.0 / n_steps)
-    noise_scale = dt * torch.sqrt(2 * eps)
-    return t, g, gd, gi, eps, dt, noise_scale
+def sde_bs(b_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torch.Tensor,
+           noise: torch.Tensor, diffuse_step: int = 10, beta_max: float = 0.03,
+           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t") -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Forward drift-score SDE (bridge_model.py:281-332): x += (b + eps*s*gamma_inv)*dt + dt*sqrt(2 eps)*d*z."""
+    delta_t = float(1.0 / diffuse_step)
+    n_steps = int(1.0 / delta_t)
+    n = x_initial.shape[0]
+    xs = [x_initial]
+    for k in range(1, n_steps + 1):
+        x = xs[-1]
+        t = torch.clip(torch.full((n,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
+        b = b_net(x, t, cond)
+        s = s_net(x, t, cond) * gamma_inv(t, gamma_type)[:, None, None]
+        dW = beta_max * noise[k - 1]
+        noise_scale = delta_t * torch.sqrt(2 * epsilon(t[0], epsilon_type))
+        new_x = x + (b + 1.0 * epsilon(t[0], epsilon_type) * s) * delta_t
+        xs.append(new_x + noise_scale * dW)
+    return xs[-1], xs
 
 
 def sde_vs(v_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torch.Tensor,

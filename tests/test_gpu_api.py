@@ -1,0 +1,161 @@
+"""GPU parity at the drop-in boundary: the mirror classes of vla-touch_amd/residual_controller (same names and
+signatures as the reference) against golden vectors captured from the reference, plus checkpoint round trips and
+the reference's error behaviour."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from tests.test_oracle_golden import SCHEDULE_CASES
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+TOL = {"fp32": 1e-4, "bf16": 1e-2}
+
+
+def G(name):
+    return np.load(f"{cases.GOLDEN}/{name}.npz")
+
+
+def err(a, b):
+    return float(np.abs(a.detach().float().cpu().numpy().astype(np.float64) - np.asarray(b, dtype=np.float64)).max())
+
+
+@pytest.fixture(scope="module")
+def controllers():
+    from residual_controller.bridge_controller import DiffusionController
+    return {p: cases.build_controller(DiffusionController, precision=p) for p in ("fp32", "bf16")}
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_predict_end_to_end_golden(controllers, prec):
+    g = G("g5_predict_e2e")
+    ctrl = controllers[prec]
+    inp = cases.predict_inputs(2, 16, 224)
+    obs = ctrl.encode_observation(inp["state"], inp["cam1"], inp["cam2"], inp["forces"])
+    pred = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"], noise=torch.from_numpy(g["z"]))
+    assert pred.shape == (2, 16, 10) and pred.dtype == torch.float32
+    e_obs, e_pred = err(obs, g["obs_cond"]), err(pred, g["pred"])
+    print(f"[{prec}] obs_cond err {e_obs:.3e}  a_hat err {e_pred:.3e}")
+    assert e_obs < (2e-4 if prec == "fp32" else 3e-2), e_obs
+    assert e_pred < TOL[prec], e_pred
+
+
+def test_predict_draws_its_own_noise(controllers):
+    ctrl = controllers["fp32"]
+    inp = cases.predict_inputs(2, 16, 224)
+    torch.manual_seed(0)
+    a = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"])
+    torch.manual_seed(0)
+    b = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"])
+    torch.manual_seed(1)
+    c = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"])
+    assert torch.equal(a, b) and not torch.equal(a, c)
+
+
+def test_checkpoint_roundtrip_reference_format(controllers):
+    from residual_controller.bridge_controller import load_bridge_controller
+    ctrl = controllers["fp32"]
+    inp = cases.predict_inputs(2, 16, 224)
+    z = torch.from_numpy(G("g5_predict_e2e")["z"])
+    ref = ctrl.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"], noise=z)
+    with tempfile.TemporaryDirectory() as d:
+        saved_stats = ctrl.stats
+        ctrl.stats = {k: v.cpu().numpy() for k, v in saved_stats.items()}      # the reference stores numpy stats
+        ctrl.save(d)
+        ctrl.stats = saved_stats
+        ck = torch.load(os.path.join(d, "controller.pt"), weights_only=False)
+        assert sorted(ck.keys()) == ["force_decoder", "model_args", "state_encoder", "stats"]
+        bm = torch.load(os.path.join(d, "bridge_model.pt"), weights_only=False)
+        assert sorted(bm.keys()) == ["ema", "net"] and sorted(bm["ema"].keys()) == ["collected_params", "decay", "num_updates", "shadow_params"]
+        assert len(bm["ema"]["shadow_params"]) == 438
+        new = load_bridge_controller(device="cuda:0", precision="fp32", image_state_dict=cases.dino_sd("small"))
+        new.load(d)
+        assert all(torch.is_tensor(v) and v.is_cuda and v.dtype == torch.float32 for v in new.stats.values())
+        out = new.predict(inp["state"], inp["vla"], inp["cam1"], inp["cam2"], inp["forces"], noise=z)
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("tag,sde,gt,et", SCHEDULE_CASES)
+def test_other_schedules_and_bs_integrator(controllers, tag, sde, gt, et):
+    g = G(f"g2_si_{tag}")
+    si = controllers["fp32"].diffusion_model
+    old = (si.sde_type, si.gamma_type, si.epsilon_type)
+    try:
+        si.sde_type, si.gamma_type, si.epsilon_type = sde, gt, et
+        x0, cond, _ = cases.si_inputs(2, 16)
+        xT, traj = si.sample(x0, cond, diffuse_step=8, recod_traj=True, noise=torch.from_numpy(g["z"]))
+        assert len(traj) == 9
+        assert err(torch.stack(traj), g["traj"]) < 1e-4, (tag, err(torch.stack(traj), g["traj"]))
+    finally:
+        si.sde_type, si.gamma_type, si.epsilon_type = old
+
+
+def test_error_behaviour_matches_reference(controllers):
+    from residual_controller.bridge.bridge_model import StochasticInterpolants
+    from residual_controller.controller_dataset import normalize_actions
+    si = controllers["fp32"].diffusion_model
+    x0, cond, _ = cases.si_inputs(2, 16)
+    old = si.gamma_type
+    si.gamma_type = "nope"
+    with pytest.raises(NotImplementedError):
+        si.gamma(torch.tensor(0.5))
+    with pytest.raises(NotImplementedError):
+        si.sample(x0, cond)
+    si.gamma_type = old
+    old = si.sde_type
+    si.sde_type = "xx"
+    with pytest.raises(NotImplementedError):
+        si.sample(x0, cond)
+    si.sde_type = old
+    with pytest.raises(ValueError):
+        normalize_actions(x0, cases.stats(), "bogus")
+    with pytest.raises(NotImplementedError):
+        StochasticInterpolants().load_model({**cases.MODEL_ARGS, "net_type": "other"}, "cuda:0")
+    with pytest.raises(RuntimeError):
+        controllers["fp32"].state_encoder.load_state_dict({"0.weight": torch.zeros(3, 3)})
+
+
+def test_unet_module_call_contract(controllers):
+    """net.v_net(sample, timestep, global_cond=cond) as the reference's sde loop calls it (bridge_model.py:352-353)."""
+    g = G("g1_unet_fwd")
+    net = controllers["fp32"].diffusion_model.net
+    x, cond = cases.unet_inputs(2, 16)
+    v = net.v_net(x, torch.full((2,), 0.5), global_cond=cond)
+    s = net.s_net(x.cuda(), 0.5, global_cond=cond)
+    assert err(v, g["v_B2_T16_t0.5"]) < 1e-4 and err(s, g["s_B2_T16_t0.5"]) < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_lstm_controller_golden(prec):
+    from residual_controller.lstm_step_controller import TactileLSTMController
+    g = G("g6_lstm")
+    c = TactileLSTMController(device="cuda:0", precision=prec, image_state_dict=cases.dino_sd("small"))
+    for name, sd in cases.lstm_mods(384).items():
+        getattr(c, name).load_state_dict(sd)
+    c.to("cuda:0")
+    c.stats = cases.stats("nontrivial")
+    li = cases.lstm_inputs(2, 16)
+    seq = c.predict_sequence(li["obs_cond"], li["vla"], li["forces"])
+    assert err(seq, g["predict_sequence"]) < 1e-4
+    assert err(c.hidden_state, g["h"]) < 1e-4 and err(c.cell_state, g["c"]) < 1e-4
+    from residual_controller.controller_dataset import normalize_actions
+    vn = normalize_actions(li["vla"], c.stats, "vla")
+    assert err(c.forward({"vla_act": vn, "obs_cond": li["obs_cond"], "forces": li["forces"]}), g["forward"]) < 1e-4
+    pi = cases.predict_inputs(2, 16, 224)
+    obs = c.encode_observation(pi["state"], pi["cam1"], pi["cam2"])
+    assert err(obs, g["obs_cond"]) < (2e-4 if prec == "fp32" else 3e-2)
+    with tempfile.TemporaryDirectory() as d:
+        c.save(d)
+        c2 = TactileLSTMController(device="cuda:0", precision=prec, image_state_dict=cases.dino_sd("small"))
+        c2.load(d)
+        assert torch.equal(c2.predict_sequence(li["obs_cond"], li["vla"], li["forces"]), seq)
+
+
+def test_no_cpu_fallback():
+    from vlatouch import _lib
+    with pytest.raises(_lib.VtError):
+        _lib.require_gpu("cpu")

@@ -1,0 +1,180 @@
+"""GPU parity: primitive kernels (through the C ABI) against plain torch fp32 references.
+Tolerances: fp32 path 1e-4-class (relative to output scale), bf16 path 1e-2-class."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from vlatouch import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rnd(shape, seed, dev, dtype=torch.float32, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def test_mfma_fragment_layouts(dev):
+    from vlatouch import ops
+    e_bf16, e_f32 = ops.mfma_selftest(dev)
+    assert e_bf16 == 0.0 and e_f32 == 0.0, (e_bf16, e_f32)
+
+
+ACTS = {0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approximate="tanh"), 3: F.silu, 4: F.mish}
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 256, 784), (70, 100, 40), (512, 512, 1280), (1000, 768, 592), (4112, 2304, 768), (33, 10, 256)])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "a32w16"])
+def test_gemm_plain(dev, M, N, K, mode):
+    from vlatouch import ops
+    adt = torch.bfloat16 if mode == "bf16" else torch.float32
+    wdt = torch.float32 if mode == "f32" else torch.bfloat16
+    a = rnd((M, K), 1, dev, adt)
+    w = rnd((N, K), 2, dev, wdt, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    cs = rnd((N,), 4, dev) + 1.0
+    act = (M + N) % 5
+    for odt in ((torch.float32,) if mode == "f32" else (torch.float32, torch.bfloat16)):
+        res = rnd((M, N), 5, dev, odt)
+        ref = res.float() + cs * ACTS[act](a.float() @ w.float().t() + bias)
+        if mode == "a32w16":
+            ref = res.float() + cs * ACTS[act](a.to(torch.bfloat16).float() @ w.float().t() + bias)
+        out = ops.gemm(a, w, bias, act=act, colscale=cs, residual=res, out_dtype=odt)
+        tol = 2e-5 if (mode == "f32") else (2e-3 if odt == torch.float32 else 1e-2)
+        assert rel_err(out.float(), ref) < tol, (mode, odt, rel_err(out.float(), ref))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+def test_gemm_splitk_slabs(dev, mode):
+    from vlatouch import ops
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    a, w = rnd((256, 2560), 1, dev, dt), rnd((512, 2560), 2, dev, dt, 2560 ** -0.5)
+    slabs = ops.gemm(a, w, splitk=5)
+    ref = a.float() @ w.float().t()
+    assert rel_err(slabs.sum(0), ref) < (2e-5 if mode == "f32" else 2e-3)
+
+
+def _pack_conv(w, cin_pad):
+    from vlatouch.engine import _conv_tapmajor
+    return _conv_tapmajor(w.cpu().float(), cin_pad)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cfg", [dict(cin=16, cout=256, k=5, T=16, stride=1), dict(cin=256, cout=512, k=5, T=8, stride=1),
+                                 dict(cin=512, cout=512, k=3, T=8, stride=2), dict(cin=1024, cout=256, k=5, T=12, stride=1)])
+def test_conv1d_implicit_gemm(dev, mode, cfg):
+    from vlatouch import ops
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    B, cin, cout, k, T, stride = 3, cfg["cin"], cfg["cout"], cfg["k"], cfg["T"], cfg["stride"]
+    x = rnd((B, T, cin), 1, dev, dt)
+    w = rnd((cout, cin, k), 2, dev, torch.float32, (cin * k) ** -0.5)
+    b = rnd((cout,), 3, dev)
+    wp = _pack_conv(w, cin).to(dt).to(dev)
+    pad = k // 2
+    tout = (T + 2 * pad - k) // stride + 1
+    out = ops.conv1d_cl(x, wp, b, taps=k, cin=cin, tout=tout, stride=stride, off0=-pad, out_dtype=torch.float32)
+    ref = F.conv1d(x.float().transpose(1, 2), w.to(dt).float(), b, stride=stride, padding=pad).transpose(1, 2)
+    assert rel_err(out, ref) < (2e-5 if mode == "f32" else 3e-3)
+
+
+def test_conv_transpose_parity_split(dev):
+    from vlatouch import ops
+    from vlatouch.engine import _convT_parity
+    B, Cc, T = 2, 256, 8
+    x = rnd((B, T, Cc), 1, dev)
+    w = rnd((Cc, Cc, 4), 2, dev, torch.float32, (Cc * 2) ** -0.5)
+    b = rnd((Cc,), 3, dev)
+    ref = F.conv_transpose1d(x.transpose(1, 2), w, b, stride=2, padding=1).transpose(1, 2)      # [B, 2T, C]
+    out = torch.empty(B, 2 * T, Cc, device=dev)
+    even = ops.conv1d_cl(x, _convT_parity(w.cpu(), (1, 3)).to(dev), b, taps=2, cin=Cc, tout=T, off0=0, tstep=-1)
+    odd = ops.conv1d_cl(x, _convT_parity(w.cpu(), (0, 2)).to(dev), b, taps=2, cin=Cc, tout=T, off0=1, tstep=-1)
+    out[:, 0::2], out[:, 1::2] = even, odd
+    assert rel_err(out, ref) < 2e-5
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("Nq,Nk,masked", [(257, 257, False), (67, 67, False), (67, 40, True), (67, 1000, False), (5, 730, False)])
+def test_attention(dev, mode, Nq, Nk, masked):
+    from vlatouch import ops
+    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    B, H = 2, 3
+    qkv = rnd((B, max(Nq, Nk), 3, H, 64), 1, dev, dt)
+    q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
+    mask = None
+    if masked:
+        mask = torch.ones(B, Nk, dtype=torch.bool, device=dev)
+        mask[0, Nk - 7:] = False
+        mask[1, 3:9] = False
+    out = ops.attention(q, k, v, kmask=mask)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) / 8.0
+    if mask is not None:
+        s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, Nq, H * 64)
+    assert rel_err(out.float(), ref) < (3e-5 if mode == "f32" else 1.5e-2)
+
+
+@pytest.mark.parametrize("T,Cc", [(16, 256), (8, 512), (4, 512), (48, 256), (64, 256)])
+def test_groupnorm_mish_film_residual(dev, T, Cc):
+    from vlatouch import ops
+    B, S = 3, 3
+    slabs = rnd((S, B * T, Cc), 1, dev)
+    bias, gamma, beta = rnd((Cc,), 2, dev), rnd((Cc,), 3, dev) + 1, rnd((Cc,), 4, dev)
+    film = rnd((B, 2 * Cc), 5, dev)
+    res = rnd((B * T, Cc), 6, dev)
+    y = (slabs.sum(0) + bias).reshape(B, T, Cc).transpose(1, 2)
+    y = F.mish(F.group_norm(y, 8, gamma, beta, 1e-5))
+    ref1 = (film[:, :Cc, None] * y + film[:, Cc:, None]).transpose(1, 2).reshape(B * T, Cc)
+    ref2 = y.transpose(1, 2).reshape(B * T, Cc) + res
+    assert rel_err(ops.groupnorm_cl(slabs, bias, gamma, beta, B=B, T=T, film=film), ref1) < 2e-5
+    assert rel_err(ops.groupnorm_cl(slabs, bias, gamma, beta, B=B, T=T, residual=res), ref2) < 2e-5
+
+
+@pytest.mark.parametrize("D", [256, 384, 768, 2048])
+def test_rownorm_modes(dev, D):
+    from vlatouch import ops, _lib as L
+    x, w, b = rnd((37, D), 1, dev), rnd((D,), 2, dev) + 1, rnd((D,), 3, dev)
+    assert rel_err(ops.rownorm(x, w, b, 1e-6), F.layer_norm(x, (D,), w, b, 1e-6)) < 2e-5
+    ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    assert rel_err(ops.rownorm(x, w, None, 1e-6, L.NORM_RMS_MEANSQ), ref) < 2e-5
+    ref = x * torch.rsqrt(x.var(-1, keepdim=True) + 1e-6) * w
+    assert rel_err(ops.rownorm(x, w, None, 1e-6, L.NORM_RMS_VAR), ref) < 2e-5
+    yb = ops.rownorm(x, w, b, 1e-6, out_dtype=torch.bfloat16)
+    assert rel_err(yb.float(), F.layer_norm(x, (D,), w, b, 1e-6)) < 1e-2
+
+
+def test_headnorm_inplace(dev):
+    from vlatouch import ops
+    x = rnd((2, 67, 3, 4, 64), 1, dev)            # fused qkv buffer [B, N, 3, H, 64]
+    w = rnd((64,), 2, dev) + 1
+    ref = x.clone()
+    ref[:, :, 0] = x[:, :, 0] * torch.rsqrt(x[:, :, 0].pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    ops.headnorm_(x, 4, w, tok_stride=3 * 4 * 64, tokens=2 * 67)      # q slice: offset 0
+    assert rel_err(x, ref) < 2e-5
+
+
+def test_action_normalize_matches_golden(dev):
+    from vlatouch.engine import action_normalize
+    g = np.load(cases.GOLDEN + "/g7_norm.npz")
+    st = cases.stats("nontrivial")
+    a = cases.predict_inputs(2, 16, 224)["vla"].to(dev)
+    for kind, key in (("vla", "n_vla"), ("expert", "n_exp")):
+        mn, mx = (st["vla_mins"], st["vla_maxs"]) if kind == "vla" else (st["action_mins"], st["action_maxs"])
+        out = action_normalize(a, mn, mx, denorm=False)
+        assert np.abs(out.cpu().numpy() - g[key]).max() < 2e-6
+        out = action_normalize(a, mn, mx, denorm=True)
+        assert np.abs(out.cpu().numpy() - g["d_" + key[2:]]).max() < 2e-6

@@ -45,6 +45,23 @@ def test_g2_si_trajectory_uses_ema_weights(T):
     close(xT, g["xT"], 5e-5, "xT")
 
 
+SCHEDULE_CASES = [("bs_sqrt_1mt2", "bs", "(2t(t-1))^0.5", "1-t^2"), ("vs_pow_sqrt", "vs", "(1-t)^2(2t)^0.5", "1-sqrt(t)"),
+                  ("vs_tt1", "vs", "2^0.5*t(t-1)", "t(t-1)")]
+
+
+@pytest.mark.parametrize("tag,sde,gt,et", SCHEDULE_CASES)
+def test_g2_other_schedules_and_bs_integrator(tag, sde, gt, et):
+    g = G(f"g2_si_{tag}")
+    sd = cases.si_net_sd("ema")
+    x0, cond, _ = cases.si_inputs(2, 16)
+    first = "b_net." if sde == "bs" else "v_net."
+    a = lambda x, t, c: ou.unet_forward(sd, first, x, t, c)
+    s = lambda x, t, c: ou.unet_forward(sd, "s_net.", x, t, c)
+    fn = oi.sde_bs if sde == "bs" else oi.sde_vs
+    _, traj = fn(a, s, x0, cond, torch.from_numpy(g["z"]), 8, 0.03, gt, et)
+    close(torch.stack(traj), g["traj"], 5e-5, tag)
+
+
 def test_g3_dino_cls():
     g = G("g3_dino_cls")
     sd = cases.dino_sd("small")

@@ -147,6 +147,16 @@ def setup():
     _stub("timm.models")
     _stub("timm.models.vision_transformer", Attention=_Attention, Mlp=_Mlp, RmsNorm=_RmsNorm,
           use_fused_attn=lambda: True)
+    # The product's mirror packages have the reference's module names (residual_controller, models): while the
+    # reference is imported, take the product directory off sys.path (vlatouch.synth stays cached in sys.modules).
+    try:
+        import vlatouch.synth  # noqa: F401
+    except ImportError:
+        pass
+    sys.path[:] = [p for p in sys.path if not p.rstrip("/").endswith("vla-touch_amd")]
+    for m in list(sys.modules):
+        if m.split(".")[0] in ("residual_controller", "models", "bridge"):
+            del sys.modules[m]
     vla = os.path.join(REF, "VLA")
     for p in (os.path.join(vla, "residual_controller"), vla):
         if p not in sys.path:

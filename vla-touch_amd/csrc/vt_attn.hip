@@ -1,0 +1,194 @@
+// vt_attn.hip — flash-style attention for head_dim 64 on gfx950 (DINOv2 self-attention, RDT self- and
+// cross-attention with an optional key mask).  One workgroup = 4 waves = 64 query rows of one (batch, head);
+// K tiles (64 keys) are staged row-major in XOR-swizzled LDS, V tiles are staged TRANSPOSED (Vt[d][key]) so
+// both MFMA operands are read as contiguous 8-element fragments.  Per wave (16 query rows):
+//   S^T tile = mfma(K_frag, Q_frag)  -> lane holds S[q = lane&15][key = kt*16 + (lane>>4)*4 + r]
+//   O^T tile = mfma(Vt_frag, P_frag) -> lane holds O[q = lane&15][d  = dt*16 + (lane>>4)*4 + r]
+// The k-index -> key assignment inside a 32-key block is (j>>2)*16 + g*4 + (j&3), which makes the P fragment
+// exactly the lane's own S registers (no cross-lane movement); Vt is read with the same assignment.
+// Online softmax state (m, l) lives per q row, replicated over the 4 lanes sharing lane&15.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+template <typename T> struct QLoad;
+template <> struct QLoad<bf16_t> {
+  __device__ static __forceinline__ void ld(Frag<bf16_t>& f, const bf16_t* p, bool ok) {
+    f.v = ok ? *reinterpret_cast<const short8_t*>(p) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+};
+template <> struct QLoad<float> {
+  __device__ static __forceinline__ void ld(Frag<float>& f, const float* p, bool ok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = ok ? p[j] : 0.f;
+  }
+};
+
+template <typename T> struct PackP;
+template <> struct PackP<bf16_t> {
+  __device__ static __forceinline__ void pack(Frag<bf16_t>& f, const float p[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(p[j]);
+  }
+};
+template <> struct PackP<float> {
+  __device__ static __forceinline__ void pack(Frag<float>& f, const float p[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = p[j];
+  }
+};
+
+template <typename T> struct VtRead;   // 4 consecutive keys of one d row
+template <> struct VtRead<bf16_t> {
+  __device__ static __forceinline__ void rd(Frag<bf16_t>& f, int half, const char* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    f.v[half * 4 + 0] = (short)(t.x & 0xffff); f.v[half * 4 + 1] = (short)(t.x >> 16);
+    f.v[half * 4 + 2] = (short)(t.y & 0xffff); f.v[half * 4 + 3] = (short)(t.y >> 16);
+  }
+};
+template <> struct VtRead<float> {
+  __device__ static __forceinline__ void rd(Frag<float>& f, int half, const char* p) {
+    const float4_t t = *reinterpret_cast<const float4_t*>(p);
+    f.v[half * 4 + 0] = t[0]; f.v[half * 4 + 1] = t[1]; f.v[half * 4 + 2] = t[2]; f.v[half * 4 + 3] = t[3];
+  }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_kernel(const VtAttnParams p) {
+  constexpr int HD = 64, KT = 64;
+  constexpr int ES = sizeof(T);
+  constexpr int EPC = Elem<T>::EPC;
+  constexpr int EPR = 128 / ES;            // elements per 128-B LDS row (64 bf16 / 32 f32)
+  constexpr int SUB = HD / EPR;            // 128-B sub-tiles per key row (1 / 2)
+  constexpr int CPK = HD / EPC;            // 16-B chunks per key row (8 / 16)
+  constexpr int VSTR = 68 * ES;            // Vt row stride in bytes (64 keys + 4 pad)
+  __shared__ __attribute__((aligned(16))) char smem[SUB * KT * 128 + HD * VSTR];
+  char* Ks = smem;
+  char* Vt = smem + SUB * KT * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 64 + wave * 16 + l15;
+  const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
+  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.km_bs : nullptr;
+
+  Frag<T> qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+
+  float4_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntiles = (p.Nk + KT - 1) / KT;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int key0 = tile * KT;
+    __syncthreads();   // previous tile fully consumed
+    // ---- stage K (row-major, swizzled) and V (transposed)
+#pragma unroll
+    for (int i = 0; i < (KT * CPK) / 256; ++i) {
+      const int ci = i * 256 + tid;
+      const int key = ci / CPK, cidx = ci - key * CPK;
+      const bool ok = key0 + key < p.Nk;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        kv = *reinterpret_cast<const uint4*>(K + (long)(key0 + key) * p.k_rs + cidx * EPC);
+        vv = *reinterpret_cast<const uint4*>(V + (long)(key0 + key) * p.v_rs + cidx * EPC);
+      }
+      const int sub = cidx >> 3, cc = cidx & 7;
+      *reinterpret_cast<uint4*>(Ks + sub * (KT * 128) + key * 128 + swz(key, cc) * 16) = kv;
+      const T* ve = reinterpret_cast<const T*>(&vv);
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) *reinterpret_cast<T*>(Vt + (cidx * EPC + j) * VSTR + key * ES) = ve[j];
+    }
+    __syncthreads();
+
+    // ---- S = K Q^T  (4 key sub-tiles of 16)
+    float4_t sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        Frag<T> kf;
+        lds_frag(kf, Ks + (d0 / EPR) * (KT * 128), kt * 16 + l15, (d0 % EPR) / 8);
+        mma16(sacc[kt], kf, qf[ks]);
+      }
+    }
+    // ---- scale, mask, online softmax
+    float sv[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int kidx = key0 + kt * 16 + g * 4 + r;
+        bool ok = kidx < p.Nk;
+        if (ok && km) ok = km[kidx] != 0;
+        const float s = ok ? sacc[kt][r] * p.scale : -INFINITY;
+        sv[kt * 4 + r] = s;
+        mx = fmaxf(mx, s);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_use);
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = expf(sv[i] - m_use); psum += sv[i]; }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    // ---- O += P V   (two 32-key blocks)
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pj[j] = sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)];
+      Frag<T> pf;
+      PackP<T>::pack(pf, pj);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Frag<T> vf;
+        const char* row = Vt + (dt * 16 + l15) * VSTR;
+        VtRead<T>::rd(vf, 0, row + (kb * 32 + g * 4) * ES);
+        VtRead<T>::rd(vf, 1, row + (kb * 32 + 16 + g * 4) * ES);
+        mma16(o[dt], vf, pf);
+      }
+    }
+  }
+  // ---- finalise
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (q < p.Nq) {
+    T* O = reinterpret_cast<T*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[dt * 16 + g * 4 + r] = Elem<T>::from_f(o[dt][r] * inv);
+  }
+}
+
+}  // namespace
+
+int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
+  const int epc = p.dtype == VT_BF16 ? 8 : 4;
+  if (p.q_rs % epc || p.k_rs % epc || p.v_rs % epc || p.q_hs % epc || p.k_hs % epc || p.v_hs % epc) return VT_ERR_ARG;
+  dim3 grid((p.Nq + 63) / 64, p.H, p.B);
+  if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, s, p);
+  return vt_check_launch();
+}

@@ -1,0 +1,107 @@
+// vt_common.h — shared device helpers for the gfx950 (CDNA4) kernels of libvlatouch_hip.so.
+// Wave = 64 lanes.  MFMA fragment convention used everywhere in this library ("8-consecutive-k"):
+//   a lane (row = lane & 15, g = lane >> 4) holds the 8 elements k = g*8 .. g*8+7 of a 32-wide k-step
+//   for BOTH operands; C/D: lane holds D[(lane>>4)*4 + r][lane & 15], r = 0..3.
+//   bf16 : one v_mfma_f32_16x16x32_bf16 per k-step.
+//   f32  : eight v_mfma_f32_16x16x4_f32 (element j of every lane = one 4-deep slice); any consistent
+//          k -> (slice, lane-group) assignment sums the same products, so both types share addressing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bits
+typedef __attribute__((ext_vector_type(8))) short short8_t;
+typedef __attribute__((ext_vector_type(4))) float float4_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+#define VT_OK 0
+#define VT_ERR_ARG (-22)
+#define VT_ERR_LAUNCH (-5)
+#define VT_ERR_UNSUPPORTED (-95)
+
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F32X3 = 2 };   // F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only)
+enum { VT_ACT_NONE = 0, VT_ACT_GELU_ERF = 1, VT_ACT_GELU_TANH = 2, VT_ACT_SILU = 3, VT_ACT_MISH = 4 };
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int EPC = 4;  // elements per 16-byte chunk
+  __device__ static __forceinline__ float to_f(float v) { return v; }
+  __device__ static __forceinline__ float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
+  __device__ static __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
+};
+
+// 8-element fragment of compute type T
+template <typename T> struct Frag;
+template <> struct Frag<bf16_t> { short8_t v; };
+template <> struct Frag<float> { float v[8]; };
+
+__device__ __forceinline__ void mma16(float4_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(float4_t& acc, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+}
+
+// read an 8-element fragment from LDS rows of 8 16-byte chunks (128 B), chunk XOR-swizzled by row.
+// `k8` = index of the 8-element group inside the row (0 .. 128/ (8*sizeof(T)) - 1).
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
+
+__device__ __forceinline__ void lds_frag(Frag<bf16_t>& f, const char* tile, int row, int k8) {
+  f.v = *reinterpret_cast<const short8_t*>(tile + row * 128 + swz(row, k8) * 16);
+}
+__device__ __forceinline__ void lds_frag(Frag<float>& f, const char* tile, int row, int k8) {
+  const float4_t lo = *reinterpret_cast<const float4_t*>(tile + row * 128 + swz(row, 2 * k8) * 16);
+  const float4_t hi = *reinterpret_cast<const float4_t*>(tile + row * 128 + swz(row, 2 * k8 + 1) * 16);
+  f.v[0] = lo[0]; f.v[1] = lo[1]; f.v[2] = lo[2]; f.v[3] = lo[3];
+  f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
+}
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+  switch (act) {
+    case VT_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    case VT_ACT_GELU_TANH: {
+      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+      return 0.5f * x * (1.0f + tanhf(u));
+    }
+    case VT_ACT_SILU: return x / (1.0f + expf(-x));
+    case VT_ACT_MISH: {
+      const float sp = x > 20.0f ? x : log1pf(expf(x));
+      return x * tanhf(sp);
+    }
+    default: return x;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// generic typed load/store as float
+template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
+template <> __device__ __forceinline__ float ldf<float>(const float* p, size_t i) { return p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+template <typename T> __device__ __forceinline__ void stf(T* p, size_t i, float v);
+template <> __device__ __forceinline__ void stf<float>(float* p, size_t i, float v) { p[i] = v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+
+static inline int vt_check_launch() { return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH; }

@@ -1,0 +1,25 @@
+// vt_gemm.h — parameter block of the generic MFMA GEMM / implicit-conv1d kernel.
+//   C[m, n] = epilogue( sum_k A'[m, k] * W[n, k] ),   W is [N, K] row-major (torch Linear layout).
+// A' is either A[m, k] (plain) or the implicit im2col of a channel-last sequence tensor
+// A[b, t, c] (conv mode):  m = b*Tout + t,  k = tap*Cin + c,
+//   A'[m, k] = A[b, t*stride + off0 + tap*tstep, c]  if that row is inside [0, Tin), else 0.
+// Grouped (z) launches: z = group*splitk + slice; each group offsets A/W/C/bias/residual by a fixed
+// element stride; each split-K slice writes a raw fp32 partial slab (no epilogue) at C + slice*c_slab.
+#pragma once
+#include <stdint.h>
+
+struct VtGemmParams {
+  const void* A; const void* W; void* C;
+  int M, N, K;
+  long lda, ldw, ldc;
+  // conv mode (taps == 0 -> plain GEMM)
+  int taps, cin, tout, tin, stride, off0, tstep;
+  // epilogue: v = acc + bias[n]; v = act(v); v *= colscale[n]; v += residual[m, n]; store
+  const float* bias; const float* colscale; const void* residual; long ldr;
+  int act;
+  // grouping / split-K
+  int groups, splitk;
+  long a_gs, w_gs, c_gs, bias_gs, r_gs;   // per-group element strides
+  long c_slab;                            // per-slice element stride of the fp32 partial slabs
+  int a_dtype, w_dtype, c_dtype;          // VT_F32 / VT_BF16 (residual has c_dtype)
+};

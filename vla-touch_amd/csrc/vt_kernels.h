@@ -1,0 +1,50 @@
+// vt_kernels.h — host launchers of the non-GEMM kernels (internal to libvlatouch_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "vt_gemm.h"
+
+enum { VT_NORM_LAYER = 0, VT_NORM_RMS_MEANSQ = 1, VT_NORM_RMS_VAR = 2 };
+enum { VT_IMGNORM_AUTO = 0, VT_IMGNORM_ON = 1, VT_IMGNORM_OFF = 2 };
+
+struct VtGnParams {
+  const float* P; int nslabs; long slab_stride; long p_gs; long ldp;   // fp32 partial slabs [slab][rows][ldp]
+  const float* bias; const float* gamma; const float* beta; long vec_gs;
+  const float* film; long film_ld; long film_off; long film_gs;         // film[net][b][off + c] = scale, [off + C + c] = bias
+  const void* residual; long ldr; long r_gs;
+  void* out; long ldo; long o_gs; int out_dtype;
+  int B, T, C, ngroups, nets;
+  float eps;
+};
+
+struct VtAttnParams {
+  const void* Q; const void* K; const void* V; void* O;
+  long q_bs, q_rs, q_hs;      // element strides: batch, row(token), head
+  long k_bs, k_rs, k_hs;
+  long v_bs, v_rs, v_hs;
+  long o_bs, o_rs;            // output [B, Nq, H*64]
+  const uint8_t* kmask; long km_bs;   // optional key mask [B, Nk] (1 = attend)
+  int B, H, Nq, Nk;
+  float scale;
+  int dtype;
+};
+
+int vt_gemm_launch(const VtGemmParams& p, hipStream_t s);
+int vt_attn_launch(const VtAttnParams& p, hipStream_t s);
+
+int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
+                 float eps, int mode, hipStream_t s);
+int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode, hipStream_t s);
+int vt_k_groupnorm(const VtGnParams& p, hipStream_t s);
+int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
+int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);
+int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
+                    float noise_scale, float d, hipStream_t s);
+int vt_k_actnorm(const float* in, float* out, const float* mins, const float* maxs, long n, int dim, float pad, int denorm, hipStream_t s);
+int vt_k_pad_cols(const float* in, int cin, void* out, int odt, int cout, long rows, hipStream_t s);
+int vt_k_place_cols(const void* src, int sdt, long lds_, void* out, int odt, long ldo, int off, int rows, int cols, hipStream_t s);
+int vt_k_bcast_row(const float* vec, float* out, long row_stride, int B, int D, hipStream_t s);
+int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s);
+int vt_k_patchify(const void* img, int is_u8, int nhwc, int B, int res, int grid_, int kpad, const float* flags, void* out, int odt, hipStream_t s);
+int vt_k_lstm_cell(const float* gi, const float* gh, float* h, float* c, int B, int H, hipStream_t s);
+int vt_k_axpby3(float* x, const void* m0, const void* m1, int mdt, float a, float b0, float b1, long n, hipStream_t s);

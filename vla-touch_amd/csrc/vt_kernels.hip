@@ -1,0 +1,418 @@
+// vt_kernels.hip — memory-bound / small kernels of the refinement path (gfx950).
+// Row-wise norms (LayerNorm / RMSNorm, one wave per row, 16-B loads), GroupNorm+Mish+FiLM+residual
+// over split-K partial slabs (one wave per (sample, group), group staged in LDS), per-head q/k RMSNorm,
+// image statistics + patchify (one HBM read of the frames), the SDE update, action (de)normalisation
+// and the small glue kernels of the U-Net / LSTM drivers.
+#include "vt_common.h"
+#include "vt_kernels.h"
+
+namespace {
+
+// ------------------------------------------------------------------ row norm (LayerNorm / RMSNorm)
+// one wave per row; D % 4 == 0; D <= 64*4*MAXV
+template <typename TI, typename TO, int MAXV>
+__global__ __launch_bounds__(256) void rownorm_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
+                                                      const float* __restrict__ w, const float* __restrict__ b,
+                                                      int rows, int D, float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const TI* xr = x + (long)row * ldx;
+  float v[MAXV][4];
+  const int nv = D >> 2;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[i][j] = ldf<TI>(xr, (size_t)c4 * 4 + j); s += v[i][j]; }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[i][j] = 0.f;
+    }
+  }
+  float mean = 0.f, var;
+  if (mode == VT_NORM_RMS_MEANSQ) {
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) q += v[i][j] * v[i][j];
+    var = wave_sum(q) / (float)D;
+  } else {
+    mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int c4 = lane + 64 * i;
+      if (c4 < nv) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+      }
+    }
+    q = wave_sum(q);
+    var = (mode == VT_NORM_RMS_VAR) ? q / (float)(D - 1) : q / (float)D;
+    if (mode == VT_NORM_RMS_VAR) mean = 0.f;   // timm<=1.0.8 rms_norm: x * rsqrt(var_unbiased(x) + eps), x not centred
+  }
+  const float rstd = rsqrtf(var + eps);
+  TO* yr = y + (long)row * ldy;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c4 = lane + 64 * i;
+    if (c4 < nv) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = c4 * 4 + j;
+        float o = (v[i][j] - mean) * rstd * w[c];
+        if (b) o += b[c];
+        stf<TO>(yr, c, o);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ per-head RMSNorm on 64-wide rows (q / k norm)
+template <typename T>
+__global__ __launch_bounds__(256) void headnorm_kernel(T* __restrict__ x, long tok_stride, int heads, long rows,
+                                                       const float* __restrict__ w, float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const long tok = r / heads;
+  const int h = (int)(r - tok * heads);
+  T* p = x + tok * tok_stride + (long)h * 64;
+  const float v = ldf<T>(p, lane);
+  float var;
+  if (mode == VT_NORM_RMS_VAR) {
+    const float mean = wave_sum(v) * (1.f / 64.f);
+    const float d = v - mean;
+    var = wave_sum(d * d) * (1.f / 63.f);
+  } else {
+    var = wave_sum(v * v) * (1.f / 64.f);
+  }
+  stf<T>(p, lane, v * rsqrtf(var + eps) * w[lane]);
+}
+
+// ------------------------------------------------------------------ GroupNorm + Mish (+FiLM) (+residual) over partial slabs
+template <typename TO>
+__global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int unit = blockIdx.x * 4 + wv;
+  const int cpg = p.C / p.ngroups;
+  const int n = cpg * p.T;
+  float* sm = gsm + (size_t)wv * n;
+  const int total = p.nets * p.B * p.ngroups;
+  if (unit >= total) return;
+  const int net = unit / (p.B * p.ngroups);
+  const int rem = unit - net * p.B * p.ngroups;
+  const int b = rem / p.ngroups, grp = rem - b * p.ngroups;
+  const float* P = p.P + (long)net * p.p_gs;
+  const float* bias = p.bias ? p.bias + (long)net * p.vec_gs : nullptr;
+  const float* gamma = p.gamma + (long)net * p.vec_gs;
+  const float* beta = p.beta + (long)net * p.vec_gs;
+  const int c0 = grp * cpg;
+  float s = 0.f;
+  for (int e = lane; e < n; e += 64) {
+    const int t = e / cpg, c = e - t * cpg;
+    const long off = ((long)b * p.T + t) * p.ldp + c0 + c;
+    float v = bias ? bias[c0 + c] : 0.f;
+    for (int k = 0; k < p.nslabs; ++k) v += P[(long)k * p.slab_stride + off];
+    sm[e] = v;
+    s += v;
+  }
+  const float mean = wave_sum(s) / (float)n;
+  float q = 0.f;
+  for (int e = lane; e < n; e += 64) { const float d = sm[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)n + p.eps);
+  const float* film = p.film ? p.film + (long)net * p.film_gs + (long)b * p.film_ld + p.film_off : nullptr;
+  const TO* R = p.residual ? reinterpret_cast<const TO*>(p.residual) + (long)net * p.r_gs : nullptr;
+  TO* O = reinterpret_cast<TO*>(p.out) + (long)net * p.o_gs;
+  for (int e = lane; e < n; e += 64) {
+    const int t = e / cpg, c = e - t * cpg, col = c0 + c;
+    float y = (sm[e] - mean) * rstd * gamma[col] + beta[col];
+    y = act_apply(y, VT_ACT_MISH);
+    if (film) y = film[col] * y + film[p.C + col];
+    const long row = (long)b * p.T + t;
+    if (R) y += Elem<TO>::to_f(R[row * p.ldr + col]);
+    O[row * p.ldo + col] = Elem<TO>::from_f(y);
+  }
+}
+
+// ------------------------------------------------------------------ small element-wise kernels
+template <typename TO>
+__global__ void sinusoid_kernel(const float* __restrict__ t, float t_host, TO* __restrict__ out, int B, int dim, int nets, long net_stride, int cos_first, float denom_minus) {
+  // out[net][b][i]: U-Net style (sin | cos, freq = exp(-i*ln(1e4)/(half-1)))  or  RDT style (cos | sin, exp(-i*ln(1e4)/half))
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int half = dim >> 1;
+  if (i >= B * dim) return;
+  const int b = i / dim, c = i - b * dim;
+  const int k = c < half ? c : c - half;
+  // U-Net: exp(k * -(ln 1e4 / (half-1))) (conditional_unet_1D.py:15-16); RDT: exp(-ln 1e4 * k / half) (blocks.py:53-56)
+  const float f = cos_first ? expf(-9.210340371976184f * (float)k / (float)half)
+                            : expf((float)k * -(9.210340371976184f / ((float)half - denom_minus)));
+  const float a = (t ? t[b] : t_host) * f;
+  const bool first = c < half;
+  const float v = (first == (cos_first != 0)) ? cosf(a) : sinf(a);
+  for (int n = 0; n < nets; ++n) out[(long)n * net_stride + i] = Elem<TO>::from_f(v);
+}
+
+template <typename TI, typename TO>
+__global__ void act_copy_kernel(const TI* __restrict__ in, long ldi, TO* __restrict__ out, long ldo, int rows, int cols, int act) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+  out[(long)r * ldo + c] = Elem<TO>::from_f(act_apply(Elem<TI>::to_f(in[(long)r * ldi + c]), act));
+}
+
+__global__ void sde_update_kernel(float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ s,
+                                  const float* __restrict__ z, long n, float dt, float gi, float gdg, float eps, float noise_scale, float d) {
+  // bridge_model.py:363-385 in the reference's operation order
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float sv = s[i] * gi;
+  const float b = v[i] - gdg * sv * eps;
+  float xn = x[i] + (b + eps * sv) * dt;
+  if (z) xn += noise_scale * (d * z[i]);
+  x[i] = xn;
+}
+
+__global__ void actnorm_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ mins,
+                               const float* __restrict__ maxs, long n, int dim, float pad, int denorm) {
+  // controller_dataset.py:303-346 (normalise: <1e-6 range guard) / :349-384 (denormalise: no guard)
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = (int)(i % dim);
+  const float mn = mins[c], mx = maxs[c];
+  const float pr = (mx - mn) * pad;
+  const float ctr = (mn + mx) / 2;
+  const float pmin = ctr - pr / 2, pmax = ctr + pr / 2;
+  float rng = pmax - pmin;
+  if (denorm) {
+    out[i] = (in[i] + 1.0f) / 2.0f * rng + pmin;
+  } else {
+    if (rng < 1e-6f) rng = 1.0f;
+    out[i] = 2.0f * (in[i] - pmin) / rng - 1.0f;
+  }
+}
+
+template <typename TO>
+__global__ void pad_cols_kernel(const float* __restrict__ in, int cin, TO* __restrict__ out, int cout, long rows) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cout) return;
+  const long r = i / cout;
+  const int c = (int)(i - r * cout);
+  out[i] = Elem<TO>::from_f(c < cin ? in[r * cin + c] : 0.f);
+}
+
+// out[r][off : off+cols] = (T) src[r][:]   (concat builder, zero padding is the caller's memset)
+template <typename TI, typename TO>
+__global__ void place_cols_kernel(const TI* __restrict__ src, long lds_, TO* __restrict__ out, long ldo, int off, int rows, int cols) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+  out[(long)r * ldo + off + c] = Elem<TO>::from_f(Elem<TI>::to_f(src[(long)r * lds_ + c]));
+}
+
+// rows[b*ld .. ] = vec (broadcast a D-vector to one row per sample: the CLS token + its position embedding)
+__global__ void bcast_row_kernel(const float* __restrict__ vec, float* __restrict__ out, long row_stride, int B, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * D) return;
+  const int b = i / D, c = i - b * D;
+  out[(long)b * row_stride + c] = vec[c];
+}
+
+// ------------------------------------------------------------------ image statistics (max, sum) -> branch flags
+template <typename TI>
+__global__ __launch_bounds__(256) void imgstat_partial_kernel(const TI* __restrict__ img, long n, float* __restrict__ part) {
+  float mx = -3.4e38f, sm = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = (float)img[i];
+    mx = fmaxf(mx, v);
+    sm += v;
+  }
+  __shared__ float smx[4], ssm[4];
+  mx = wave_max(mx);
+  sm = wave_sum(sm);
+  if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; ssm[threadIdx.x >> 6] = sm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    part[2 * blockIdx.x + 1] = (ssm[0] + ssm[1]) + (ssm[2] + ssm[3]);
+  }
+}
+// flags[0] = pixel scale (1 or 1/255), flags[1] = 1.0 if ImageNet normalisation applies (visual_encoder.py:78,100)
+__global__ void imgstat_final_kernel(const float* __restrict__ part, int nparts, long n, float pre_scale, int norm_mode, float* __restrict__ flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float mx = -3.4e38f;
+  double sm = 0.0;
+  for (int i = 0; i < nparts; ++i) { mx = fmaxf(mx, part[2 * i]); sm += (double)part[2 * i + 1]; }
+  mx *= pre_scale;
+  float scale = pre_scale;
+  if (mx > 1.0f) scale = pre_scale / 255.0f;
+  const float mean = (float)(sm / (double)n) * scale;
+  flags[0] = scale;
+  flags[1] = norm_mode == VT_IMGNORM_AUTO ? (mean < 0.5f ? 0.f : 1.f) : (norm_mode == VT_IMGNORM_ON ? 1.f : 0.f);
+  flags[2] = mx;
+  flags[3] = mean;
+}
+
+// ------------------------------------------------------------------ patchify: frames -> A[b*np + p][c*196 + i*14 + j] (K padded)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ img, int nhwc, int B, int res, int grid_, int kpad,
+                                                       const float* __restrict__ flags, TO* __restrict__ out) {
+  // one block per (image, patch row): reads 14 full image rows per channel -> coalesced along W
+  const int b = blockIdx.x / grid_, py = blockIdx.x - b * grid_;
+  const float scale = flags[0];
+  const bool norm = flags[1] != 0.f;
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
+  const int W14 = grid_ * 14;   // used width (res may exceed grid*14; HF conv drops the remainder)
+  const int total = 3 * 14 * W14;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    int c, i, xcol;
+    if (nhwc) { i = e / (W14 * 3); const int r = e - i * W14 * 3; xcol = r / 3; c = r - xcol * 3; }
+    else      { c = e / (14 * W14); const int r = e - c * 14 * W14; i = r / W14; xcol = r - i * W14; }
+    const int yrow = py * 14 + i;
+    const long src = nhwc ? (((long)b * res + yrow) * res + xcol) * 3 + c : (((long)b * 3 + c) * res + yrow) * res + xcol;
+    float v = (float)img[src] * scale;
+    if (norm) v = (v - mean[c]) * istd[c];
+    const int px = xcol / 14, j = xcol - px * 14;
+    out[((long)(b * grid_ + py) * grid_ + px) * kpad + c * 196 + i * 14 + j] = Elem<TO>::from_f(v);
+  }
+  // zero the K padding of this patch row
+  const int padn = kpad - 588;
+  for (int e = threadIdx.x; e < grid_ * padn; e += 256) {
+    const int px = e / padn, k = e - px * padn;
+    out[((long)(b * grid_ + py) * grid_ + px) * kpad + 588 + k] = Elem<TO>::from_f(0.f);
+  }
+}
+
+// ------------------------------------------------------------------ LSTM cell (gates pre-computed by two GEMMs)
+__global__ void lstm_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh, float* __restrict__ h, float* __restrict__ c, int B, int H) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * H) return;
+  const int b = i / H, j = i - b * H;
+  const float* a = gi + (long)b * 4 * H;
+  const float* r = gh + (long)b * 4 * H;
+  const float ig = 1.f / (1.f + expf(-(a[j] + r[j])));
+  const float fg = 1.f / (1.f + expf(-(a[H + j] + r[H + j])));
+  const float gg = tanhf(a[2 * H + j] + r[2 * H + j]);
+  const float og = 1.f / (1.f + expf(-(a[3 * H + j] + r[3 * H + j])));
+  const float cn = fg * c[i] + ig * gg;
+  c[i] = cn;
+  h[i] = og * tanhf(cn);
+}
+
+// DPM-Solver++ step on [n] elements: x = a*x + b0*m0 + b1*m1  (x fp32 master, xb = bf16/f32 copy for the next forward)
+template <typename TM>
+__global__ void axpby3_kernel(float* __restrict__ x, const TM* __restrict__ m0, const TM* __restrict__ m1, float a, float b0, float b1, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float v = a * x[i] + b0 * Elem<TM>::to_f(m0[i]);
+  if (m1) v += b1 * Elem<TM>::to_f(m1[i]);
+  x[i] = v;
+}
+
+inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+}  // namespace
+
+// =============================================================================== host launchers
+#define DISPATCH_T(dt, T, ...) \
+  if ((dt) == VT_F32) { using T = float; __VA_ARGS__; } else { using T = bf16_t; __VA_ARGS__; }
+
+int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
+                 float eps, int mode, hipStream_t s) {
+  if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
+  dim3 grid((rows + 3) / 4);
+  DISPATCH_T(xdt, TI, DISPATCH_T(ydt, TO, {
+    if (D <= 1024) hipLaunchKernelGGL((rownorm_kernel<TI, TO, 4>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode);
+    else hipLaunchKernelGGL((rownorm_kernel<TI, TO, 8>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode);
+  }))
+  return vt_check_launch();
+}
+
+int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode, hipStream_t s) {
+  const long rows = tokens * heads;
+  if (rows <= 0) return VT_ERR_ARG;
+  DISPATCH_T(dt, T, hipLaunchKernelGGL((headnorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (T*)x, tok_stride, heads, rows, w, eps, mode))
+  return vt_check_launch();
+}
+
+int vt_k_groupnorm(const VtGnParams& p, hipStream_t s) {
+  if (p.C % p.ngroups) return VT_ERR_ARG;
+  const int n = (p.C / p.ngroups) * p.T;
+  const size_t smem = (size_t)4 * n * sizeof(float);
+  if (smem > 64 * 1024) return VT_ERR_UNSUPPORTED;
+  const int units = p.nets * p.B * p.ngroups;
+  DISPATCH_T(p.out_dtype, TO, hipLaunchKernelGGL((gn_kernel<TO>), dim3((units + 3) / 4), dim3(256), smem, s, p))
+  return vt_check_launch();
+}
+
+int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s) {
+  DISPATCH_T(odt, TO, hipLaunchKernelGGL((sinusoid_kernel<TO>), g1((long)B * dim), dim3(256), 0, s, t, t_host, (TO*)out, B, dim, nets, net_stride,
+                                         rdt_style, rdt_style ? 0.f : 1.f))
+  return vt_check_launch();
+}
+
+int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s) {
+  DISPATCH_T(idt, TI, DISPATCH_T(odt, TO, hipLaunchKernelGGL((act_copy_kernel<TI, TO>), g1((long)rows * cols), dim3(256), 0, s, (const TI*)in, ldi,
+                                                              (TO*)out, ldo, rows, cols, act)))
+  return vt_check_launch();
+}
+
+int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
+                    float noise_scale, float d, hipStream_t s) {
+  hipLaunchKernelGGL(sde_update_kernel, g1(n), dim3(256), 0, s, x, v, sc, z, n, dt, gi, gdg, eps, noise_scale, d);
+  return vt_check_launch();
+}
+
+int vt_k_actnorm(const float* in, float* out, const float* mins, const float* maxs, long n, int dim, float pad, int denorm, hipStream_t s) {
+  hipLaunchKernelGGL(actnorm_kernel, g1(n), dim3(256), 0, s, in, out, mins, maxs, n, dim, pad, denorm);
+  return vt_check_launch();
+}
+
+int vt_k_pad_cols(const float* in, int cin, void* out, int odt, int cout, long rows, hipStream_t s) {
+  DISPATCH_T(odt, TO, hipLaunchKernelGGL((pad_cols_kernel<TO>), g1(rows * cout), dim3(256), 0, s, in, cin, (TO*)out, cout, rows))
+  return vt_check_launch();
+}
+
+int vt_k_place_cols(const void* src, int sdt, long lds_, void* out, int odt, long ldo, int off, int rows, int cols, hipStream_t s) {
+  DISPATCH_T(sdt, TI, DISPATCH_T(odt, TO, hipLaunchKernelGGL((place_cols_kernel<TI, TO>), g1((long)rows * cols), dim3(256), 0, s, (const TI*)src, lds_,
+                                                              (TO*)out, ldo, off, rows, cols)))
+  return vt_check_launch();
+}
+
+int vt_k_bcast_row(const float* vec, float* out, long row_stride, int B, int D, hipStream_t s) {
+  hipLaunchKernelGGL(bcast_row_kernel, g1((long)B * D), dim3(256), 0, s, vec, out, row_stride, B, D);
+  return vt_check_launch();
+}
+
+int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s) {
+  const int nb = 256;
+  if (is_u8) hipLaunchKernelGGL((imgstat_partial_kernel<uint8_t>), dim3(nb), dim3(256), 0, s, (const uint8_t*)img, n, part);
+  else hipLaunchKernelGGL((imgstat_partial_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)img, n, part);
+  hipLaunchKernelGGL(imgstat_final_kernel, dim3(1), dim3(64), 0, s, part, nb, n, pre_scale, norm_mode, flags);
+  return vt_check_launch();
+}
+
+int vt_k_patchify(const void* img, int is_u8, int nhwc, int B, int res, int grid_, int kpad, const float* flags, void* out, int odt, hipStream_t s) {
+  if (kpad < 588) return VT_ERR_ARG;
+  dim3 grid(B * grid_);
+  DISPATCH_T(odt, TO, {
+    if (is_u8) hipLaunchKernelGGL((patchify_kernel<uint8_t, TO>), grid, dim3(256), 0, s, (const uint8_t*)img, nhwc, B, res, grid_, kpad, flags, (TO*)out);
+    else hipLaunchKernelGGL((patchify_kernel<float, TO>), grid, dim3(256), 0, s, (const float*)img, nhwc, B, res, grid_, kpad, flags, (TO*)out);
+  })
+  return vt_check_launch();
+}
+
+int vt_k_lstm_cell(const float* gi, const float* gh, float* h, float* c, int B, int H, hipStream_t s) {
+  hipLaunchKernelGGL(lstm_cell_kernel, g1((long)B * H), dim3(256), 0, s, gi, gh, h, c, B, H);
+  return vt_check_launch();
+}
+
+int vt_k_axpby3(float* x, const void* m0, const void* m1, int mdt, float a, float b0, float b1, long n, hipStream_t s) {
+  DISPATCH_T(mdt, TM, hipLaunchKernelGGL((axpby3_kernel<TM>), g1(n), dim3(256), 0, s, x, (const TM*)m0, (const TM*)m1, a, b0, b1, n))
+  return vt_check_launch();
+}

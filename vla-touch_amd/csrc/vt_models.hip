@@ -1,0 +1,259 @@
+// vt_models.hip — host drivers: DINOv2 CLS encoder, small MLP chains, observation concat, LSTM residual head.
+//
+// DINOv2 weight order (vt_dino_create):
+//   0 patch_w [D][kpad] cdt   1 patch_b [D]   2 cls_pos0 [D] (= cls_token + position_embeddings[0])
+//   per layer (14 entries): ln1_w ln1_b  qkv_w [3D][D] cdt  qkv_b [3D]  proj_w [D][D] cdt  proj_b  ls1
+//                           ln2_w ln2_b  fc1_w [4D][D] cdt  fc1_b  fc2_w [D][4D] cdt  fc2_b  ls2
+//   then  lnf_w  lnf_b
+// The residual stream (tokens) is kept in fp32; normalised activations / QKV / MLP hidden are `adt`.
+//
+// LSTM weight order (vt_lstm_create):
+//   0 fe_w1 [H/2][force_pad] cdt  1 fe_b1  2 fe_w2 [H/2][H/2] cdt  3 fe_b2
+//   per layer: w_ih [4H][in_pad_l] cdt  w_hh [4H][H] cdt  b_ih  b_hh      (in_pad_0 = in_pad, else H)
+//   then head_w1 [H][2H] cdt  head_b1  ln_w  ln_b  head_w2 [state_dim][H] cdt  head_b2
+#include <math.h>
+#include <string.h>
+#include <new>
+#include "vt_common.h"
+#include "vt_kernels.h"
+#include "vt_host.h"
+#include "../../include/vlatouch.h"
+
+#define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
+static int es(int dt) { return dt == VT_BF16 ? 2 : 4; }
+
+static VtGemmParams lin(const void* A, int adt, long lda, const void* W, int cdt, long ldw, const float* b, void* C, int odt, long ldc,
+                        int M, int N, int K, int act) {
+  VtGemmParams p;
+  memset(&p, 0, sizeof(p));
+  p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
+  p.bias = b; p.act = act; p.groups = 1; p.splitk = 1; p.a_dtype = adt; p.w_dtype = cdt; p.c_dtype = odt;
+  return p;
+}
+
+// ======================================================================================= DINOv2
+struct DinoLayer {
+  const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ls1, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls2;
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+};
+struct vt_dino_s {
+  vt_dino_desc d;
+  const void* patch_w; const float *patch_b, *cls_pos0, *lnf_w, *lnf_b;
+  DinoLayer L[48];
+};
+
+int vt_dino_num_weights(const vt_dino_desc* d) { return 3 + 14 * d->layers + 2; }
+
+int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_dino_t* out) {
+  if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_dino_create: null argument");
+  const vt_dino_desc& d = *desc;
+  if (d.layers < 1 || d.layers > 48 || d.hidden % 64 || d.hidden / d.heads != 64 || d.patch != 14 || d.kpad % 16 || d.kpad < 588)
+    return vt_fail(VT_ERR_ARG, "vt_dino_create: unsupported config (head_dim must be 64, patch 14)");
+  if (n != vt_dino_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_dino_create: expected %d weights, got %d", vt_dino_num_weights(desc), n);
+  for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_dino_create: weight %d is null", k);
+  vt_dino_s* h = new (std::nothrow) vt_dino_s();
+  if (!h) return vt_fail(-12, "out of host memory");
+  h->d = d;
+  int i = 0;
+  h->patch_w = w[i++]; h->patch_b = (const float*)w[i++]; h->cls_pos0 = (const float*)w[i++];
+  for (int l = 0; l < d.layers; ++l) {
+    DinoLayer& L = h->L[l];
+    L.ln1_w = (const float*)w[i++]; L.ln1_b = (const float*)w[i++]; L.qkv_w = w[i++]; L.qkv_b = (const float*)w[i++];
+    L.proj_w = w[i++]; L.proj_b = (const float*)w[i++]; L.ls1 = (const float*)w[i++];
+    L.ln2_w = (const float*)w[i++]; L.ln2_b = (const float*)w[i++]; L.fc1_w = w[i++]; L.fc1_b = (const float*)w[i++];
+    L.fc2_w = w[i++]; L.fc2_b = (const float*)w[i++]; L.ls2 = (const float*)w[i++];
+  }
+  h->lnf_w = (const float*)w[i++]; h->lnf_b = (const float*)w[i++];
+  *out = h;
+  return VT_OK;
+}
+void vt_dino_destroy(vt_dino_t h) { delete h; }
+
+namespace {
+struct DWs { size_t part, flags, apatch, tok, xn, qkv, att, h1, total; };
+DWs dcarve(const vt_dino_s* h, int Bt, int res) {
+  const vt_dino_desc& d = h->d;
+  const int a = es(d.adt), g = res / d.patch, N = g * g + 1, D = d.hidden;
+  DWs w; size_t o = 0;
+  auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
+  w.part = take(512 * 4 * 8); w.flags = take(8 * 4 * 8);
+  w.apatch = take((size_t)Bt * g * g * d.kpad * a);
+  w.tok = take((size_t)Bt * N * D * 4);
+  w.xn = take((size_t)Bt * N * D * a);
+  w.qkv = take((size_t)Bt * N * 3 * D * a);
+  w.att = take((size_t)Bt * N * D * a);
+  w.h1 = take((size_t)Bt * N * 4 * D * a);
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+size_t vt_dino_workspace_bytes(vt_dino_t h, int B_total, int res) { return h ? dcarve(h, B_total, res).total : 0; }
+
+int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, int nhwc, float pre_scale, int norm_mode, int B, int res,
+                    const float* pos_patch, float* out, float* flags_out, void* workspace, vt_stream_t stream) {
+  if (!h || !imgs || !pos_patch || !out || !workspace) return vt_fail(VT_ERR_ARG, "vt_dino_forward: null argument");
+  if (ncams < 1 || ncams > 8 || B < 1 || res < 14) return vt_fail(VT_ERR_ARG, "vt_dino_forward: bad sizes");
+  const vt_dino_desc& d = h->d;
+  hipStream_t s = (hipStream_t)stream;
+  const int g = res / d.patch, np = g * g, N = np + 1, D = d.hidden, Bt = ncams * B, a = es(d.adt);
+  char* ws = (char*)workspace;
+  const DWs w = dcarve(h, Bt, res);
+  float* tok = (float*)(ws + w.tok);
+  // 1. per-camera statistics -> branch flags; patchify with the camera's own decision
+  for (int c = 0; c < ncams; ++c) {
+    float* part = (float*)(ws + w.part) + c * 512;
+    float* flags = (float*)(ws + w.flags) + c * 8;
+    const long n = (long)B * 3 * res * res;
+    CK(vt_wrap(vt_k_imgstats(imgs[c], is_u8, n, pre_scale, norm_mode, part, flags, s), "dino imgstats"));
+    CK(vt_wrap(vt_k_patchify(imgs[c], is_u8, nhwc, B, res, g, d.kpad, flags, ws + w.apatch + (size_t)c * B * np * d.kpad * a, d.adt, s), "dino patchify"));
+    if (flags_out && hipMemcpyAsync(flags_out + c * 4, flags, 16, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "flags copy");
+  }
+  // 2. patch-embed GEMM, one group per image, + position embedding (shared residual) -> fp32 tokens rows 1..np
+  {
+    VtGemmParams p = lin(ws + w.apatch, d.adt, d.kpad, h->patch_w, d.cdt, d.kpad, h->patch_b, tok + D, VT_F32, D, np, D, d.kpad, VT_ACT_NONE);
+    p.groups = Bt; p.a_gs = (long)np * d.kpad; p.w_gs = 0; p.c_gs = (long)N * D; p.bias_gs = 0;
+    p.residual = pos_patch; p.ldr = D; p.r_gs = 0;
+    CK(vt_wrap(vt_gemm_launch(p, s), "dino patch embed"));
+    CK(vt_k_bcast_row(h->cls_pos0, tok, (long)N * D, Bt, D, s));
+  }
+  const int M = Bt * N;
+  for (int l = 0; l < d.layers; ++l) {
+    const DinoLayer& L = h->L[l];
+    CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln1_w, L.ln1_b, M, D, d.eps, VT_NORM_LAYER, s));
+    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino qkv")); }
+    { VtAttnParams p;
+      memset(&p, 0, sizeof(p));
+      p.Q = ws + w.qkv; p.K = ws + w.qkv + (size_t)D * a; p.V = ws + w.qkv + (size_t)2 * D * a; p.O = ws + w.att;
+      p.q_bs = p.k_bs = p.v_bs = (long)N * 3 * D; p.q_rs = p.k_rs = p.v_rs = 3 * D; p.q_hs = p.k_hs = p.v_hs = 64;
+      p.o_bs = (long)N * D; p.o_rs = D;
+      p.B = Bt; p.H = d.heads; p.Nq = N; p.Nk = N; p.scale = 0.125f; p.dtype = d.adt;
+      CK(vt_wrap(vt_attn_launch(p, s), "dino attention")); }
+    { VtGemmParams p = lin(ws + w.att, d.adt, D, L.proj_w, d.cdt, D, L.proj_b, tok, VT_F32, D, M, D, D, VT_ACT_NONE);
+      p.colscale = L.ls1; p.residual = tok; p.ldr = D;
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino proj")); }
+    CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln2_w, L.ln2_b, M, D, d.eps, VT_NORM_LAYER, s));
+    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, 4 * D, M, 4 * D, D, VT_ACT_GELU_ERF);
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
+    { VtGemmParams p = lin(ws + w.h1, d.adt, 4 * D, L.fc2_w, d.cdt, 4 * D, L.fc2_b, tok, VT_F32, D, M, D, 4 * D, VT_ACT_NONE);
+      p.colscale = L.ls2; p.residual = tok; p.ldr = D;
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2")); }
+  }
+  // 3. final LayerNorm on the CLS rows only -> pooler_output
+  CK(vt_k_rownorm(tok, VT_F32, (long)N * D, out, VT_F32, D, h->lnf_w, h->lnf_b, Bt, D, d.eps, VT_NORM_LAYER, s));
+  return VT_OK;
+}
+
+// ======================================================================================= MLP chain / concat
+int vt_mlp(const void* x, long ldx, int B, int n_layers, const int* dims, const void* const* W, const float* const* b, int act,
+           void* y, int ydt, long ldy, int cdt, int adt, void* tmp, vt_stream_t stream) {
+  if (!x || !dims || !W || !b || !y || n_layers < 1 || n_layers > 8) return vt_fail(VT_ERR_ARG, "vt_mlp: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  int mx = 0;
+  for (int i = 1; i < n_layers; ++i) mx = dims[i] > mx ? dims[i] : mx;
+  if (n_layers > 1 && !tmp) return vt_fail(VT_ERR_ARG, "vt_mlp: tmp required");
+  const void* cur = x; long ld = ldx;
+  for (int i = 0; i < n_layers; ++i) {
+    const bool last = i == n_layers - 1;
+    void* dst = last ? y : (char*)tmp + (size_t)(i & 1) * B * mx * es(adt);
+    VtGemmParams p = lin(cur, adt, ld, W[i], cdt, dims[i], b[i], dst, last ? ydt : adt, last ? ldy : dims[i + 1], B, dims[i + 1], dims[i],
+                         last ? VT_ACT_NONE : act);
+    CK(vt_wrap(vt_gemm_launch(p, s), "vt_mlp layer"));
+    cur = dst; ld = dims[i + 1];
+  }
+  return VT_OK;
+}
+
+int vt_concat_obs(const float* cls1, const float* cls2, int dv, const float* state, int sdim, const float* forces, int fdim,
+                  void* out, int odt, long ldo, int B, vt_stream_t stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(out, 0, (size_t)B * ldo * es(odt), s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "memset");
+  CK(vt_k_place_cols(cls1, VT_F32, dv, out, odt, ldo, 0, B, dv, s));
+  CK(vt_k_place_cols(cls2, VT_F32, dv, out, odt, ldo, dv, B, dv, s));
+  CK(vt_k_place_cols(state, VT_F32, sdim, out, odt, ldo, 2 * dv, B, sdim, s));
+  if (forces && fdim > 0) CK(vt_k_place_cols(forces, VT_F32, fdim, out, odt, ldo, 2 * dv + sdim, B, fdim, s));
+  return VT_OK;
+}
+
+// ======================================================================================= LSTM residual head
+struct vt_lstm_s {
+  vt_lstm_desc d;
+  const void *fe_w1, *fe_w2, *w_ih[4], *w_hh[4], *head_w1, *head_w2;
+  const float *fe_b1, *fe_b2, *b_ih[4], *b_hh[4], *head_b1, *ln_w, *ln_b, *head_b2;
+};
+int vt_lstm_num_weights(const vt_lstm_desc* d) { return 4 + 4 * d->layers + 6; }
+int vt_lstm_create(const vt_lstm_desc* desc, const void* const* w, int n, vt_lstm_t* out) {
+  if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_lstm_create: null argument");
+  const vt_lstm_desc& d = *desc;
+  if (d.layers < 1 || d.layers > 4 || d.hidden % 32 || d.in_pad % 16 || d.force_pad % 16) return vt_fail(VT_ERR_ARG, "vt_lstm_create: bad descriptor");
+  if (n != vt_lstm_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_lstm_create: expected %d weights, got %d", vt_lstm_num_weights(desc), n);
+  for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_lstm_create: weight %d is null", k);
+  vt_lstm_s* h = new (std::nothrow) vt_lstm_s();
+  if (!h) return vt_fail(-12, "out of host memory");
+  h->d = d;
+  int i = 0;
+  h->fe_w1 = w[i++]; h->fe_b1 = (const float*)w[i++]; h->fe_w2 = w[i++]; h->fe_b2 = (const float*)w[i++];
+  for (int l = 0; l < d.layers; ++l) { h->w_ih[l] = w[i++]; h->w_hh[l] = w[i++]; h->b_ih[l] = (const float*)w[i++]; h->b_hh[l] = (const float*)w[i++]; }
+  h->head_w1 = w[i++]; h->head_b1 = (const float*)w[i++]; h->ln_w = (const float*)w[i++]; h->ln_b = (const float*)w[i++];
+  h->head_w2 = w[i++]; h->head_b2 = (const float*)w[i++];
+  *out = h;
+  return VT_OK;
+}
+void vt_lstm_destroy(vt_lstm_t h) { delete h; }
+
+namespace {
+struct LWs { size_t fpad, f1, xin, gi, gh, hc, hd1, hd2, total; };
+LWs lcarve(const vt_lstm_s* h, int B) {
+  const vt_lstm_desc& d = h->d;
+  LWs w; size_t o = 0;
+  auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
+  w.fpad = take((size_t)B * d.force_pad * 4); w.f1 = take((size_t)B * d.hidden / 2 * 4);
+  w.xin = take((size_t)B * d.in_pad * 4);
+  w.gi = take((size_t)B * 4 * d.hidden * 4); w.gh = take((size_t)B * 4 * d.hidden * 4);
+  w.hc = take((size_t)B * 2 * d.hidden * 4); w.hd1 = take((size_t)B * d.hidden * 4); w.hd2 = take((size_t)B * d.hidden * 4);
+  w.total = o;
+  return w;
+}
+}  // namespace
+size_t vt_lstm_workspace_bytes(vt_lstm_t h, int B) { return h ? lcarve(h, B).total : 0; }
+
+int vt_lstm_step(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c, float* out_n, int B,
+                 void* workspace, vt_stream_t stream) {
+  if (!hd || !obs_cond || !vla_n || !force || !h || !c || !out_n || !workspace) return vt_fail(VT_ERR_ARG, "vt_lstm_step: null argument");
+  const vt_lstm_desc& d = hd->d;
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  const LWs w = lcarve(hd, B);
+  const int H = d.hidden, H2 = d.hidden / 2;
+  // activations stay fp32 (tiny, latency-bound); weights cdt
+  CK(vt_k_pad_cols(force, d.force_dim, ws + w.fpad, VT_F32, d.force_pad, B, s));
+  { VtGemmParams p = lin(ws + w.fpad, VT_F32, d.force_pad, hd->fe_w1, d.cdt, d.force_pad, hd->fe_b1, ws + w.f1, VT_F32, H2, B, H2, d.force_pad, VT_ACT_GELU_ERF);
+    CK(vt_wrap(vt_gemm_launch(p, s), "lstm force mlp 1")); }
+  if (hipMemsetAsync(ws + w.xin, 0, (size_t)B * d.in_pad * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "memset");
+  { VtGemmParams p = lin(ws + w.f1, VT_F32, H2, hd->fe_w2, d.cdt, H2, hd->fe_b2, ws + w.xin, VT_F32, d.in_pad, B, H2, H2, VT_ACT_NONE);
+    CK(vt_wrap(vt_gemm_launch(p, s), "lstm force mlp 2")); }
+  CK(vt_k_place_cols(vla_n, VT_F32, d.state_dim, ws + w.xin, VT_F32, d.in_pad, H2, B, d.state_dim, s));
+  const void* xin = ws + w.xin; int xk = d.in_pad;
+  for (int l = 0; l < d.layers; ++l) {
+    float* hl = h + (long)l * B * H;
+    float* cl = c + (long)l * B * H;
+    { VtGemmParams p = lin(xin, VT_F32, xk, hd->w_ih[l], d.cdt, xk, hd->b_ih[l], ws + w.gi, VT_F32, 4 * H, B, 4 * H, xk, VT_ACT_NONE);
+      CK(vt_wrap(vt_gemm_launch(p, s), "lstm w_ih")); }
+    { VtGemmParams p = lin(hl, VT_F32, H, hd->w_hh[l], d.cdt, H, hd->b_hh[l], ws + w.gh, VT_F32, 4 * H, B, 4 * H, H, VT_ACT_NONE);
+      CK(vt_wrap(vt_gemm_launch(p, s), "lstm w_hh")); }
+    CK(vt_k_lstm_cell((const float*)(ws + w.gi), (const float*)(ws + w.gh), hl, cl, B, H, s));
+    xin = hl; xk = H;
+  }
+  // head: cat(h_top, obs_cond) -> Linear -> LayerNorm -> GELU -> Linear ; + vla_n
+  CK(vt_k_place_cols(xin, VT_F32, H, ws + w.hc, VT_F32, 2 * H, 0, B, H, s));
+  CK(vt_k_place_cols(obs_cond, VT_F32, H, ws + w.hc, VT_F32, 2 * H, H, B, H, s));
+  { VtGemmParams p = lin(ws + w.hc, VT_F32, 2 * H, hd->head_w1, d.cdt, 2 * H, hd->head_b1, ws + w.hd1, VT_F32, H, B, H, 2 * H, VT_ACT_NONE);
+    CK(vt_wrap(vt_gemm_launch(p, s), "lstm head 1")); }
+  CK(vt_k_rownorm(ws + w.hd1, VT_F32, H, ws + w.hd2, VT_F32, H, hd->ln_w, hd->ln_b, B, H, 1e-5f, VT_NORM_LAYER, s));
+  CK(vt_k_act_copy(ws + w.hd2, VT_F32, H, ws + w.hd1, VT_F32, H, B, H, VT_ACT_GELU_ERF, s));
+  { VtGemmParams p = lin(ws + w.hd1, VT_F32, H, hd->head_w2, d.cdt, H, hd->head_b2, out_n, VT_F32, d.state_dim, B, d.state_dim, H, VT_ACT_NONE);
+    p.residual = vla_n; p.ldr = d.state_dim;
+    CK(vt_wrap(vt_gemm_launch(p, s), "lstm head 2")); }
+  return VT_OK;
+}

@@ -1,0 +1,177 @@
+"""Stochastic-interpolant sampler — mirror of the reference's
+VLA/residual_controller/bridge/bridge_model.py:28-446 (inference surface).
+
+Kept from the reference: the constructor / `load_model_args` contract, the string-keyed schedules
+(`epsilon`, `gamma`, `gamma_der`, `gamma_inv`, NotImplementedError on unknown keys, :59-101), `sample(x_prior,
+cond, diffuse_step=10, recod_traj=False)` (:259-279) which samples under the EMA shadow weights, the
+`sde_vs` / `sde_bs` integrators (:281-387, forward direction), `load_model` / `save_model` and the
+`bridge_model.pt` = {"net", "ema"} checkpoint format (:421-446), `train()` / `eval()`.
+Not kept (training-only, out of scope per SURVEY §2 row 2): the losses, q_sample, interpolant().
+
+The whole n-step Euler–Maruyama loop is ONE call into the HIP engine (vt_si_sample): v_net and s_net are
+evaluated in grouped launches, the SDE update is a fused element-wise kernel.  The reference draws its
+Gaussian noise with torch.randn_like inside the loop; here the same draws are made up-front
+(`noise=` lets a caller inject them — that is how parity with the reference is tested).
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import torch
+
+from vlatouch.module import ExponentialMovingAverage, default_precision
+from residual_controller.bridge.networks.conditional_unet_1D_si import InterpolantsConditionalUnet1D
+
+_GAMMA = {"2^0.5*t(t-1)": 0, "(2t(t-1))^0.5": 1, "(1-t)^2(2t)^0.5": 2}
+_EPS = {"1-t": 0, "t(t-1)": 1, "1-sqrt(t)": 2, "1-t^2": 3, "0": 4}
+
+
+class StochasticInterpolants:
+    def __init__(self, model_args=None, precision: Optional[str] = None):
+        self.precision = precision or default_precision()
+        self.net = None
+        self.ema = None
+        self._sampler = None
+        if model_args:
+            self.load_model_args(model_args)
+        else:
+            print("init SI without model args")
+
+    def load_model_args(self, model_args):
+        self.interpolant_type = model_args['interpolant_type']
+        self.gamma_type = model_args['gamma_type']
+        self.epsilon_type = model_args['epsilon_type']
+        self.prior_policy = model_args['prior_policy']
+        self.d = model_args['beta_max']
+        self.t_min = 0.001
+        self.gamma_inv_max = 200.0
+        self.net = None
+        self.ema = None
+        self.prior_model = None
+        self._sampler = None
+        self.sde_type = model_args['sde_type'] if 'sde_type' in model_args else 'vs'
+
+    # ---- schedules (host-side scalar definitions; the sampler evaluates the same formulas per step in C)
+    def epsilon(self, t):
+        if self.epsilon_type == 't(t-1)':
+            return t * (1 - t)
+        elif self.epsilon_type == '1-t':
+            return (1 - t) * 1.0
+        elif self.epsilon_type == '1-sqrt(t)':
+            return 1 - torch.sqrt(t)
+        elif self.epsilon_type == '1-t^2':
+            return 1 - torch.pow(t, 2)
+        elif self.epsilon_type == '0':
+            return t * 0.0
+        raise NotImplementedError
+
+    def gamma(self, t):
+        if self.gamma_type == '(2t(t-1))^0.5':
+            return 1.4142 * torch.sqrt(t * (1 - t))
+        elif self.gamma_type == '2^0.5*t(t-1)':
+            return 1.4142 * t * (1 - t)
+        elif self.gamma_type == '(1-t)^2(2t)^0.5':
+            return 1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t)
+        raise NotImplementedError
+
+    def gamma_der(self, t):
+        if self.gamma_type == '(2t(t-1))^0.5':
+            return (1 - 2 * t) / torch.sqrt(2 * (t - torch.pow(t, 2)) + 1e-4)
+        if self.gamma_type == '2^0.5*t(t-1)':
+            return 1.4142 * (1 - 2 * t)
+        elif self.gamma_type == '(1-t)^2(2t)^0.5':
+            return 1.4142 * (2 * (t - 1) * torch.sqrt(t) + torch.pow((1 - t), 2.0) / (2.0 * torch.sqrt(t + 1e-4)))
+        raise NotImplementedError
+
+    def gamma_inv(self, t):
+        if self.gamma_type == '(2t(t-1))^0.5':
+            return torch.clamp(1 / (1.4142 * torch.sqrt(t * (1 - t) + 1e-4)), 0.0, self.gamma_inv_max)
+        elif self.gamma_type == '2^0.5*t(t-1)':
+            return torch.clamp(1 / (1.4142 * t * (1 - t) + 1e-4), 0.0, self.gamma_inv_max)
+        elif self.gamma_type == '(1-t)^2(2t)^0.5':
+            return torch.clamp(1 / (1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t) + 1e-4), 0.0, self.gamma_inv_max)
+        raise NotImplementedError
+
+    # ---- sampling
+    def _sampler_engine(self, nets, device):
+        """U-Net pair engine built from the EMA shadow parameters (what `with self.ema.average_parameters()` makes the
+        reference sample with, bridge_model.py:267).  Cached until the EMA state or the net is reloaded."""
+        key = (tuple(nets), self.ema.version, self.net.version, str(device))
+        if self._sampler is None or self._sampler[0] != key:
+            from vlatouch.engine import UNetEngine
+            names = list(self.net._params.keys())
+            shadow = dict(zip(names, self.ema.shadow_params))
+            sds = [{k[len(n) + 1:]: v for k, v in shadow.items() if k.startswith(n + ".")} for n in nets]
+            eng = UNetEngine(sds, device=device, precision=self.precision, **self.net.cfg)
+            self._sampler = (key, eng)
+        return self._sampler[1]
+
+    def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise):
+        if direction != 'forward':
+            raise NotImplementedError("only the forward direction is used by sample() and implemented here")
+        if score_weight != 1.0:
+            raise NotImplementedError("score_weight != 1.0")
+        if self.gamma_type not in _GAMMA or self.epsilon_type not in _EPS:
+            raise NotImplementedError
+        n_steps = int(1.0 / delta_t)
+        dev = x_initial.device if x_initial.device.type == "cuda" else torch.device("cuda")
+        if noise is None:   # the reference's `self.d * torch.randn_like(current_x)` draws, made up-front
+            noise = torch.randn((n_steps,) + tuple(x_initial.shape), dtype=torch.float32, device=dev)
+        eng = self._sampler_engine(nets, dev)
+        xT, traj = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=True,
+                              gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code)
+        return xT, [traj[i] for i in range(traj.shape[0])]
+
+    def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None):
+        return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise)
+
+    def sde_bs(self, b_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None):
+        return self._run(("b_net", "s_net"), 1, x_initial, cond, delta_t, score_weight, direction, noise)
+
+    def sample(self, x_prior, cond, diffuse_step=10, recod_traj=False, noise=None):
+        """x_prior (batch, T, dim) normalised prior actions, cond (batch, obs_dim) -> refined normalised actions."""
+        with torch.no_grad():
+            if self.sde_type == 'vs':
+                x_target, x_target_traj = self.sde_vs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise)
+            elif self.sde_type == 'bs':
+                x_target, x_target_traj = self.sde_bs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise)
+            else:
+                raise NotImplementedError
+        if recod_traj:
+            return x_target, x_target_traj
+        return x_target
+
+    def train(self):
+        if self.net is not None:
+            self.net.train()
+        return self
+
+    def eval(self):
+        if self.net is not None:
+            self.net.eval()
+        return self
+
+    def load_model(self, model_args, device):
+        self.load_model_args(model_args)
+        if model_args['net_type'] == 'unet1D_si':
+            self.net = InterpolantsConditionalUnet1D(
+                input_dim=model_args['action_dim'],
+                global_cond_dim=model_args['obs_dim'] * model_args['obs_horizon'],
+                precision=self.precision,
+            )
+        else:
+            raise NotImplementedError
+        self.ema = ExponentialMovingAverage(self.net.parameters(), decay=0.75).bind(self.net)
+        if model_args['pretrain']:
+            checkpoint = torch.load(os.path.join(model_args['ckpt_path'], "bridge_model.pt"), map_location="cpu", weights_only=False)
+            self.net.load_state_dict(checkpoint['net'])
+            self.ema.load_state_dict(checkpoint["ema"])
+        self.net.to(device)
+        self.ema.to(device)
+        self._sampler = None
+
+    def save_model(self, ckpt_path):
+        torch.save({"net": {k: v.cpu() for k, v in self.net.state_dict().items()},
+                    "ema": {**self.ema.state_dict(), "shadow_params": [p.cpu() for p in self.ema.shadow_params]}},
+                   os.path.join(ckpt_path, "bridge_model.pt"))

@@ -1,0 +1,180 @@
+"""ctypes binding of libvlatouch_hip.so (include/vlatouch.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every computation of the
+refinement path is a call into the HIP library.  There is NO CPU / eager fallback: if the
+library is missing, or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvlatouch_hip.so")
+
+F32, BF16, F32X3 = 0, 1, 2   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only)
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4
+NORM_LAYER, NORM_RMS_MEANSQ, NORM_RMS_VAR = 0, 1, 2
+IMGNORM_AUTO, IMGNORM_ON, IMGNORM_OFF = 0, 1, 2
+
+
+class VtError(RuntimeError):
+    pass
+
+
+class GemmParams(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("W", C.c_void_p), ("C", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("lda", C.c_long), ("ldw", C.c_long), ("ldc", C.c_long),
+        ("taps", C.c_int), ("cin", C.c_int), ("tout", C.c_int), ("tin", C.c_int), ("stride", C.c_int),
+        ("off0", C.c_int), ("tstep", C.c_int),
+        ("bias", C.c_void_p), ("colscale", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_long),
+        ("act", C.c_int),
+        ("groups", C.c_int), ("splitk", C.c_int),
+        ("a_gs", C.c_long), ("w_gs", C.c_long), ("c_gs", C.c_long), ("bias_gs", C.c_long), ("r_gs", C.c_long),
+        ("c_slab", C.c_long),
+        ("a_dtype", C.c_int), ("w_dtype", C.c_int), ("c_dtype", C.c_int),
+    ]
+
+
+class GnParams(C.Structure):
+    _fields_ = [
+        ("P", C.c_void_p), ("nslabs", C.c_int), ("slab_stride", C.c_long), ("p_gs", C.c_long), ("ldp", C.c_long),
+        ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("vec_gs", C.c_long),
+        ("film", C.c_void_p), ("film_ld", C.c_long), ("film_off", C.c_long), ("film_gs", C.c_long),
+        ("residual", C.c_void_p), ("ldr", C.c_long), ("r_gs", C.c_long),
+        ("out", C.c_void_p), ("ldo", C.c_long), ("o_gs", C.c_long), ("out_dtype", C.c_int),
+        ("B", C.c_int), ("T", C.c_int), ("C", C.c_int), ("ngroups", C.c_int), ("nets", C.c_int),
+        ("eps", C.c_float),
+    ]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("O", C.c_void_p),
+        ("q_bs", C.c_long), ("q_rs", C.c_long), ("q_hs", C.c_long),
+        ("k_bs", C.c_long), ("k_rs", C.c_long), ("k_hs", C.c_long),
+        ("v_bs", C.c_long), ("v_rs", C.c_long), ("v_hs", C.c_long),
+        ("o_bs", C.c_long), ("o_rs", C.c_long),
+        ("kmask", C.c_void_p), ("km_bs", C.c_long),
+        ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int),
+        ("scale", C.c_float), ("dtype", C.c_int),
+    ]
+
+
+class UnetDesc(C.Structure):
+    _fields_ = [("nets", C.c_int), ("input_dim", C.c_int), ("input_pad", C.c_int), ("cond_dim", C.c_int),
+                ("dsed", C.c_int), ("n_groups", C.c_int), ("ksize", C.c_int), ("n_levels", C.c_int),
+                ("dims", C.c_int * 4), ("cdt", C.c_int), ("adt", C.c_int)]
+
+
+class DinoDesc(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("patch", C.c_int), ("kpad", C.c_int),
+                ("cdt", C.c_int), ("adt", C.c_int), ("eps", C.c_float)]
+
+
+class LstmDesc(C.Structure):
+    _fields_ = [("state_dim", C.c_int), ("hidden", C.c_int), ("layers", C.c_int), ("force_dim", C.c_int),
+                ("force_pad", C.c_int), ("in_pad", C.c_int), ("cdt", C.c_int)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (fails loudly: the product has no other compute path)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VtError(f"{LIB_PATH} not found — build it with `python __graft_entry__.py` (hipcc --offload-arch=gfx950). "
+                      "vlatouch has no CPU/eager fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.vt_last_error.restype = C.c_char_p
+    L.vt_version.restype = C.c_int
+    for name, (res, args) in SIGNATURES.items():
+        if not hasattr(L, name):
+            raise VtError(f"{LIB_PATH} does not export {name} (stale build?)")
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_size_t
+# every entry point of include/vlatouch.h: name -> (restype, argtypes)
+SIGNATURES = {
+    "vt_selftest_mfma": (_I, [_P, _P]),
+    "vt_prof_enable": (_I, [_I]),
+    "vt_prof_collect": (_I, [_P, _P, _P, _P]),
+    "vt_gemm": (_I, [_P, _P]),
+    "vt_attention": (_I, [_P, _P]),
+    "vt_groupnorm": (_I, [_P, _P]),
+    "vt_rownorm": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _I, _I, _F, _I, _P]),
+    "vt_headnorm": (_I, [_P, _I, _L, _I, _L, _P, _F, _I, _P]),
+    "vt_action_normalize": (_I, [_P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "vt_unet_create": (_I, [_P, _P, _I, _P]),
+    "vt_unet_destroy": (None, [_P]),
+    "vt_unet_num_weights": (_I, [_P]),
+    "vt_unet_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_unet_forward": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P, _P]),
+    "vt_si_sample": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _I, _P, _P]),
+    "vt_dino_create": (_I, [_P, _P, _I, _P]),
+    "vt_dino_destroy": (None, [_P]),
+    "vt_dino_num_weights": (_I, [_P]),
+    "vt_dino_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_dino_forward": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "vt_mlp": (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
+    "vt_concat_obs": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P]),
+    "vt_lstm_create": (_I, [_P, _P, _I, _P]),
+    "vt_lstm_destroy": (None, [_P]),
+    "vt_lstm_num_weights": (_I, [_P]),
+    "vt_lstm_workspace_bytes": (_Z, [_P, _I]),
+    "vt_lstm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+}
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        raise VtError(f"{what or 'vlatouch'} failed with code {code}: {lib().vt_last_error().decode()}")
+
+
+def stream_ptr(device=None) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def dt_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise VtError(f"unsupported dtype {dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def ptr_array(tensors: Sequence[Optional[torch.Tensor]]):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = 0 if t is None else t.data_ptr()
+    return arr
+
+
+def require_gpu(device) -> torch.device:
+    device = torch.device(device)
+    if device.type != "cuda" or not torch.cuda.is_available():
+        raise VtError("vlatouch runs only on an AMD GPU through libvlatouch_hip.so (device must be 'cuda'; "
+                      "no CPU fallback exists)")
+    lib()
+    return device

@@ -1,0 +1,440 @@
+"""Engines: frozen-weight packing (load time) + handles into libvlatouch_hip.so (run time).
+
+Each engine takes a plain state dict (the reference's checkpoint key layout),
+re-lays the weights once for the gfx950 kernels (tap-major implicit-GEMM conv weights, fused QKV,
+parity-split ConvTranspose, K padded to 16), keeps them resident in HBM and drives the C ABI.
+torch is used for allocation, one-time weight re-layout and stream handles only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Mapping, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+SD = Mapping[str, torch.Tensor]
+
+
+def _pad_to(n: int, m: int = 16) -> int:
+    return (n + m - 1) // m * m
+
+
+def precision_dtypes(precision: str):
+    """'fp32': fp32 weights + activations (fp32 MFMA, 1e-4 parity).  'bf16': bf16 weights, fp32 accumulate."""
+    if precision == "fp32":
+        return L.F32, L.F32
+    if precision == "bf16":
+        return L.BF16, L.BF16
+    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+
+
+class _Workspace:
+    def __init__(self, device):
+        self.device = device
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+# =========================================================================================== U-Net / SI sampler
+def _conv_tapmajor(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
+    """Conv1d weight [Cout, Cin, k] -> [Cout, k*cin_pad] with W'[co, tap*cin_pad + ci] = w[co, ci, tap]."""
+    cout, cin, k = w.shape
+    o = torch.zeros(cout, k, cin_pad, dtype=w.dtype)
+    o[:, :, :cin] = w.permute(0, 2, 1)
+    return o.reshape(cout, k * cin_pad)
+
+
+def _convT_parity(w: torch.Tensor, taps) -> torch.Tensor:
+    """ConvTranspose1d weight [Cin, Cout, 4] -> [Cout, 2*Cin] for the given pair of kernel taps."""
+    return torch.cat([w[:, :, t].t() for t in taps], dim=1).contiguous()
+
+
+class UNetEngine:
+    """`nets` structurally identical conditional 1-D U-Nets evaluated together (v_net + s_net for the sampler).
+
+    sds: one state dict per net with keys relative to the net (e.g. 'down_modules.0.0.blocks.0.block.0.weight').
+    """
+
+    def __init__(self, sds: Sequence[SD], *, input_dim: int = 10, global_cond_dim: int = 256, dsed: int = 256,
+                 down_dims: Sequence[int] = (256, 512, 512), kernel_size: int = 5, n_groups: int = 8,
+                 precision: str = "fp32", act_dtype: Optional[str] = None, device="cuda"):
+        self.device = L.require_gpu(device)
+        self.nets = len(sds)
+        # precision: 'fp32'       exact fp32 MFMA (v_mfma_f32_16x16x4_f32), 1e-4 parity
+        #            'bf16'       split-bf16: fp32 storage, a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on the bf16 MFMA pipe
+        #                         (the SDE multiplies the score by up to ~8/step, plain bf16 misses the 1e-2 bar)
+        #            'bf16_plain' bf16 weights + activations, one bf16 MFMA per k-step (fastest, ~2.5e-2 on a_hat)
+        if precision == "bf16":
+            cdt, adt = L.F32X3, L.F32
+        elif precision == "bf16_plain":
+            cdt, adt = L.BF16, L.BF16
+        else:
+            cdt, adt = precision_dtypes(precision)
+        if act_dtype is not None:
+            adt = {"fp32": L.F32, "bf16": L.BF16}[act_dtype]
+        self.cdt, self.adt = cdt, adt
+        self.input_dim, self.cond_dim, self.dsed = input_dim, global_cond_dim, dsed
+        self.dims = list(down_dims)
+        self.k = kernel_size
+        wdt = torch.bfloat16 if cdt == L.BF16 else torch.float32
+        Lv = len(self.dims)
+        all_dims = [input_dim] + self.dims
+        rbs = []
+        for l in range(Lv):
+            rbs.append((f"down_modules.{l}.0", all_dims[l], self.dims[l]))
+            rbs.append((f"down_modules.{l}.1", self.dims[l], self.dims[l]))
+        rbs.append(("mid_modules.0", self.dims[-1], self.dims[-1]))
+        rbs.append(("mid_modules.1", self.dims[-1], self.dims[-1]))
+        for u in range(Lv - 1):
+            din, dout = self.dims[Lv - 2 - u], self.dims[Lv - 1 - u]
+            rbs.append((f"up_modules.{u}.0", 2 * dout, din))
+            rbs.append((f"up_modules.{u}.1", din, din))
+
+        # cache CPU fp32 copies once
+        cpu = [{k: v.detach().float().cpu() for k, v in sd.items()} for sd in sds]
+
+        def st(fn, dtype):
+            return torch.stack([fn(sd) for sd in cpu]).to(dtype).contiguous().to(self.device)
+
+        f32 = torch.float32
+        W: List[Optional[torch.Tensor]] = []
+        W.append(st(lambda sd: sd["diffusion_step_encoder.1.weight"], wdt))
+        W.append(st(lambda sd: sd["diffusion_step_encoder.1.bias"], f32))
+        W.append(st(lambda sd: sd["diffusion_step_encoder.3.weight"], wdt))
+        W.append(st(lambda sd: sd["diffusion_step_encoder.3.bias"], f32))
+        W.append(st(lambda sd: torch.cat([sd[f"{p}.cond_encoder.1.weight"] for p, _, _ in rbs], dim=0), wdt))
+        W.append(st(lambda sd: torch.cat([sd[f"{p}.cond_encoder.1.bias"] for p, _, _ in rbs], dim=0), f32))
+        for p, cin, cout in rbs:
+            cpad = _pad_to(cin)
+            W.append(st(lambda sd: _conv_tapmajor(sd[f"{p}.blocks.0.block.0.weight"], cpad), wdt))
+            W.append(st(lambda sd: sd[f"{p}.blocks.0.block.0.bias"], f32))
+            W.append(st(lambda sd: sd[f"{p}.blocks.0.block.1.weight"], f32))
+            W.append(st(lambda sd: sd[f"{p}.blocks.0.block.1.bias"], f32))
+            W.append(st(lambda sd: _conv_tapmajor(sd[f"{p}.blocks.1.block.0.weight"], cout), wdt))
+            W.append(st(lambda sd: sd[f"{p}.blocks.1.block.0.bias"], f32))
+            W.append(st(lambda sd: sd[f"{p}.blocks.1.block.1.weight"], f32))
+            W.append(st(lambda sd: sd[f"{p}.blocks.1.block.1.bias"], f32))
+            if cin != cout:
+                W.append(st(lambda sd: _conv_tapmajor(sd[f"{p}.residual_conv.weight"], cpad), wdt))
+                W.append(st(lambda sd: sd[f"{p}.residual_conv.bias"], f32))
+            else:
+                W += [None, None]
+        for l in range(Lv - 1):
+            W.append(st(lambda sd: _conv_tapmajor(sd[f"down_modules.{l}.2.conv.weight"], self.dims[l]), wdt))
+            W.append(st(lambda sd: sd[f"down_modules.{l}.2.conv.bias"], f32))
+        for u in range(Lv - 1):
+            W.append(st(lambda sd: _convT_parity(sd[f"up_modules.{u}.2.conv.weight"], (1, 3)), wdt))
+            W.append(st(lambda sd: _convT_parity(sd[f"up_modules.{u}.2.conv.weight"], (0, 2)), wdt))
+            W.append(st(lambda sd: sd[f"up_modules.{u}.2.conv.bias"], f32))
+        W.append(st(lambda sd: _conv_tapmajor(sd["final_conv.0.block.0.weight"], self.dims[0]), wdt))
+        W.append(st(lambda sd: sd["final_conv.0.block.0.bias"], f32))
+        W.append(st(lambda sd: sd["final_conv.0.block.1.weight"], f32))
+        W.append(st(lambda sd: sd["final_conv.0.block.1.bias"], f32))
+        W.append(st(lambda sd: sd["final_conv.1.weight"][:, :, 0], wdt))
+        W.append(st(lambda sd: sd["final_conv.1.bias"], f32))
+        self._weights = W      # keep alive: the handle stores raw device pointers
+
+        desc = L.UnetDesc()
+        desc.nets, desc.input_dim, desc.input_pad = self.nets, input_dim, _pad_to(input_dim)
+        desc.cond_dim, desc.dsed, desc.n_groups, desc.ksize, desc.n_levels = global_cond_dim, dsed, n_groups, kernel_size, Lv
+        for i, d in enumerate(self.dims):
+            desc.dims[i] = d
+        desc.cdt, desc.adt = cdt, adt
+        lib = L.lib()
+        n = lib.vt_unet_num_weights(C.byref(desc))
+        assert n == len(W), (n, len(W))
+        self._h = C.c_void_p()
+        L.check(lib.vt_unet_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_unet_create")
+        self._ws = _Workspace(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().vt_unet_destroy(self._h)
+        except Exception:
+            pass
+
+    def _workspace(self, B: int, T: int) -> torch.Tensor:
+        return self._ws.get(L.lib().vt_unet_workspace_bytes(self._h, B, T))
+
+    def forward(self, x: torch.Tensor, t, cond: torch.Tensor) -> torch.Tensor:
+        """x [B,T,dim], t scalar or [B], cond [B,G]  ->  [nets,B,T,dim] fp32."""
+        B, T, D = x.shape
+        x = x.to(self.device, torch.float32).contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        out = torch.empty(self.nets, B, T, D, dtype=torch.float32, device=self.device)
+        if torch.is_tensor(t) and t.numel() > 1:
+            tdev = t.to(self.device, torch.float32).contiguous()
+            tp, th = L.ptr(tdev), 0.0
+        else:
+            tp, th = C.c_void_p(0), float(t)
+        ws = self._workspace(B, T)
+        L.check(L.lib().vt_unet_forward(self._h, L.ptr(x), tp, C.c_float(th), L.ptr(cond), L.ptr(out), B, T, L.ptr(ws),
+                                        L.stream_ptr(self.device)), "vt_unet_forward")
+        return out
+
+    def sample(self, x0: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], n_steps: int, beta_max: float,
+               record: bool = False, gamma_type: int = 0, epsilon_type: int = 0, sde_type: int = 0):
+        """Forward velocity-score SDE from x0 (normalised actions).  Returns xT (and the n_steps+1 states)."""
+        B, T, D = x0.shape
+        x = x0.to(self.device, torch.float32).clone().contiguous()
+        cond = cond.to(self.device, torch.float32).contiguous()
+        if noise is not None:
+            noise = noise.to(self.device, torch.float32).contiguous()
+            assert tuple(noise.shape) == (n_steps, B, T, D), noise.shape
+        traj = torch.empty(n_steps + 1, B, T, D, dtype=torch.float32, device=self.device) if record else None
+        ws = self._workspace(B, T)
+        L.check(L.lib().vt_si_sample(self._h, L.ptr(x), L.ptr(cond), L.ptr(noise), n_steps, C.c_float(beta_max), gamma_type, epsilon_type,
+                                     sde_type, L.ptr(traj), B, T, L.ptr(ws), L.stream_ptr(self.device)), "vt_si_sample")
+        return (x, traj) if record else x
+
+
+# =========================================================================================== DINOv2
+class DinoEngine:
+    """HF Dinov2Model state dict -> CLS features (pooler_output)."""
+
+    def __init__(self, sd: SD, *, heads: int, precision: str = "fp32", device="cuda", patch: int = 14, eps: float = 1e-6):
+        self.device = L.require_gpu(device)
+        cdt, adt = precision_dtypes(precision)
+        self.cdt, self.adt = cdt, adt
+        wdt = L.torch_dtype(cdt)
+        f32 = torch.float32
+        g = lambda k: sd[k].detach().float().cpu()
+        pw = g("embeddings.patch_embeddings.projection.weight")
+        D = pw.shape[0]
+        self.hidden, self.heads, self.patch = D, heads, patch
+        self.kpad = _pad_to(3 * patch * patch)
+        layers = 0
+        while f"encoder.layer.{layers}.norm1.weight" in sd:
+            layers += 1
+        self.layers = layers
+        dev = self.device
+        pwp = torch.zeros(D, self.kpad)
+        pwp[:, : 3 * patch * patch] = pw.reshape(D, -1)
+        self._pos_full = g("embeddings.position_embeddings")            # [1, 1+n, D] fp32 (CPU)
+        cls_pos0 = (g("embeddings.cls_token")[0, 0] + self._pos_full[0, 0]).contiguous()
+        W: List[torch.Tensor] = [pwp.to(wdt).to(dev), g("embeddings.patch_embeddings.projection.bias").to(dev), cls_pos0.to(dev)]
+        for i in range(layers):
+            p = f"encoder.layer.{i}"
+            a = f"{p}.attention.attention"
+            qkv_w = torch.cat([g(f"{a}.query.weight"), g(f"{a}.key.weight"), g(f"{a}.value.weight")], dim=0)
+            qkv_b = torch.cat([g(f"{a}.query.bias"), g(f"{a}.key.bias"), g(f"{a}.value.bias")], dim=0)
+            W += [g(f"{p}.norm1.weight").to(dev), g(f"{p}.norm1.bias").to(dev), qkv_w.to(wdt).contiguous().to(dev), qkv_b.to(dev),
+                  g(f"{p}.attention.output.dense.weight").to(wdt).to(dev), g(f"{p}.attention.output.dense.bias").to(dev),
+                  g(f"{p}.layer_scale1.lambda1").to(dev),
+                  g(f"{p}.norm2.weight").to(dev), g(f"{p}.norm2.bias").to(dev),
+                  g(f"{p}.mlp.fc1.weight").to(wdt).to(dev), g(f"{p}.mlp.fc1.bias").to(dev),
+                  g(f"{p}.mlp.fc2.weight").to(wdt).to(dev), g(f"{p}.mlp.fc2.bias").to(dev),
+                  g(f"{p}.layer_scale2.lambda1").to(dev)]
+        W += [g("layernorm.weight").to(dev), g("layernorm.bias").to(dev)]
+        W = [w.contiguous() for w in W]
+        self._weights = W
+        desc = L.DinoDesc()
+        desc.hidden, desc.layers, desc.heads, desc.patch, desc.kpad = D, layers, heads, patch, self.kpad
+        desc.cdt, desc.adt, desc.eps = cdt, adt, eps
+        lib = L.lib()
+        assert lib.vt_dino_num_weights(C.byref(desc)) == len(W)
+        self._h = C.c_void_p()
+        L.check(lib.vt_dino_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_dino_create")
+        self._ws = _Workspace(self.device)
+        self._pos_cache: Dict[int, torch.Tensor] = {}
+        self.last_flags: Optional[torch.Tensor] = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().vt_dino_destroy(self._h)
+        except Exception:
+            pass
+
+    def pos_patch(self, grid: int) -> torch.Tensor:
+        """Position embeddings of the patch tokens for a grid x grid image: input-independent, so the bicubic
+        resize of HF `interpolate_pos_encoding` (modeling_dinov2.py:57-95) is done once per resolution at load."""
+        if grid not in self._pos_cache:
+            pos = self._pos_full
+            n = pos.shape[1] - 1
+            s = int(round(math.sqrt(n)))
+            pp = pos[:, 1:]
+            if grid * grid != n:
+                pp = pp.reshape(1, s, s, -1).permute(0, 3, 1, 2)
+                pp = F.interpolate(pp, size=(grid, grid), mode="bicubic", align_corners=False)
+                pp = pp.permute(0, 2, 3, 1).reshape(1, grid * grid, -1)
+            self._pos_cache[grid] = pp[0].contiguous().to(self.device)
+        return self._pos_cache[grid]
+
+    def forward(self, cams: Sequence[torch.Tensor], *, nhwc: bool, pre_scale: float = 1.0, norm_mode: int = L.IMGNORM_AUTO) -> torch.Tensor:
+        """cams: list of image batches (same shape/dtype, fp32 or uint8) -> [ncams, B, hidden] fp32.
+        Each camera batch gets its own max()/mean() decision (visual_encoder.py:78,100)."""
+        x0 = cams[0]
+        is_u8 = x0.dtype == torch.uint8
+        cams = [c.to(self.device).contiguous() if is_u8 else c.to(self.device, torch.float32).contiguous() for c in cams]
+        B = cams[0].shape[0]
+        res = cams[0].shape[1] if nhwc else cams[0].shape[2]
+        for c in cams:
+            assert c.shape == cams[0].shape
+            assert (c.shape[1] == c.shape[2]) if nhwc else (c.shape[2] == c.shape[3]), "square frames only"
+        grid = res // self.patch
+        n = len(cams)
+        out = torch.empty(n, B, self.hidden, dtype=torch.float32, device=self.device)
+        flags = torch.empty(n, 4, dtype=torch.float32, device=self.device)
+        lib = L.lib()
+        ws = self._ws.get(lib.vt_dino_workspace_bytes(self._h, n * B, res))
+        L.check(lib.vt_dino_forward(self._h, L.ptr_array(cams), n, int(is_u8), int(nhwc), C.c_float(pre_scale), norm_mode, B, res,
+                                    L.ptr(self.pos_patch(grid)), L.ptr(out), L.ptr(flags), L.ptr(ws), L.stream_ptr(self.device)),
+                "vt_dino_forward")
+        self.last_flags = flags
+        return out
+
+
+# =========================================================================================== MLP chain
+class MlpEngine:
+    """nn.Sequential(Linear, act, Linear, act, ..., Linear) with torch-style keys '0.weight', '2.weight', ..."""
+
+    def __init__(self, sd: SD, *, act: int = L.ACT_GELU_ERF, precision: str = "fp32", device="cuda"):
+        self.device = L.require_gpu(device)
+        self.cdt, self.adt = precision_dtypes(precision)
+        wdt = L.torch_dtype(self.cdt)
+        idx = sorted(int(k.split(".")[0]) for k in sd if k.endswith(".weight") and sd[k].dim() == 2)
+        self.W, self.b, dims = [], [], []
+        for j, i in enumerate(idx):
+            w = sd[f"{i}.weight"].detach().float().cpu()
+            kin = _pad_to(w.shape[1])
+            if j > 0:
+                assert w.shape[1] == dims[-1] or kin == dims[-1]
+            wp = torch.zeros(w.shape[0], kin)
+            wp[:, : w.shape[1]] = w
+            if j == 0:
+                dims.append(kin)
+                self.in_features = w.shape[1]
+            assert w.shape[0] % 4 == 0 or j == len(idx) - 1
+            dims.append(_pad_to(w.shape[0]) if j < len(idx) - 1 else w.shape[0])
+            if j < len(idx) - 1 and dims[-1] != w.shape[0]:
+                wp = torch.cat([wp, torch.zeros(dims[-1] - w.shape[0], kin)], dim=0)
+            self.W.append(wp.to(wdt).contiguous().to(self.device))
+            bb = sd[f"{i}.bias"].detach().float().cpu()
+            if bb.numel() < dims[-1]:
+                bb = torch.cat([bb, torch.zeros(dims[-1] - bb.numel())])
+            self.b.append(bb.contiguous().to(self.device))
+        self.dims = dims
+        self.act = act
+        self.out_features = dims[-1]
+        self.in_pad = dims[0]
+        self._dims_c = (C.c_int * len(dims))(*dims)
+        self._Wp = L.ptr_array(self.W)
+        self._bp = L.ptr_array(self.b)
+        self._tmp = None
+
+    def __call__(self, x: torch.Tensor, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+        """x: [B, in_pad] of the activation dtype (zero padded)."""
+        B = x.shape[0]
+        assert x.shape[1] == self.in_pad and x.dtype == L.torch_dtype(self.adt) and x.is_contiguous()
+        y = torch.empty(B, self.out_features, dtype=out_dtype, device=self.device)
+        mx = max(self.dims[1:-1]) if len(self.dims) > 2 else 1
+        need = 2 * B * mx
+        if self._tmp is None or self._tmp.numel() < need:
+            self._tmp = torch.empty(need, dtype=L.torch_dtype(self.adt), device=self.device)
+        L.check(L.lib().vt_mlp(L.ptr(x), x.shape[1], B, len(self.W), self._dims_c, self._Wp, self._bp, self.act, L.ptr(y),
+                               L.dt_code(out_dtype), self.out_features, self.cdt, self.adt, L.ptr(self._tmp), L.stream_ptr(self.device)),
+                "vt_mlp")
+        return y
+
+    def pad_input(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        xp = torch.zeros(B, self.in_pad, dtype=L.torch_dtype(self.adt), device=self.device)
+        xp[:, : x.shape[1]] = x.to(self.device)
+        return xp
+
+
+def concat_obs(cls1, cls2, state, forces, in_pad: int, adt: int, device) -> torch.Tensor:
+    """[cls_cam1 | cls_cam2 | state | forces] -> zero-padded [B, in_pad] activation matrix (bridge_controller.py:129-132)."""
+    B, dv = cls1.shape
+    out = torch.empty(B, in_pad, dtype=L.torch_dtype(adt), device=device)
+    state = state.to(device, torch.float32).contiguous()
+    fd = 0
+    if forces is not None:
+        forces = forces.to(device, torch.float32).contiguous()
+        fd = forces.shape[1]
+    L.check(L.lib().vt_concat_obs(L.ptr(cls1), L.ptr(cls2), dv, L.ptr(state), state.shape[1], L.ptr(forces), fd, L.ptr(out), adt,
+                                  in_pad, B, L.stream_ptr(device)), "vt_concat_obs")
+    return out
+
+
+def action_normalize(x: torch.Tensor, mins: torch.Tensor, maxs: torch.Tensor, denorm: bool, padding_factor: float = 1.4) -> torch.Tensor:
+    x = x.to(torch.float32).contiguous()
+    dev = x.device
+    mins = mins.to(dev, torch.float32).contiguous()
+    maxs = maxs.to(dev, torch.float32).contiguous()
+    out = torch.empty_like(x)
+    L.check(L.lib().vt_action_normalize(L.ptr(x), L.ptr(out), L.ptr(mins), L.ptr(maxs), x.numel(), x.shape[-1],
+                                        C.c_float(padding_factor), int(denorm), L.stream_ptr(dev)), "vt_action_normalize")
+    return out
+
+
+# =========================================================================================== LSTM residual head
+class LstmEngine:
+    def __init__(self, mods: Mapping[str, SD], *, state_dim: int = 10, hidden: int = 256, layers: int = 2, force_dim: int = 3,
+                 precision: str = "fp32", device="cuda"):
+        self.device = L.require_gpu(device)
+        cdt, _ = precision_dtypes(precision)
+        self.cdt = cdt
+        wdt = L.torch_dtype(cdt)
+        dev = self.device
+        H = hidden
+        self.state_dim, self.hidden, self.layers = state_dim, hidden, layers
+        fpad, inpad = _pad_to(force_dim), _pad_to(H // 2 + state_dim)
+
+        def padk(w, k):
+            o = torch.zeros(w.shape[0], k)
+            o[:, : w.shape[1]] = w
+            return o
+
+        g = lambda m, k: mods[m][k].detach().float().cpu()
+        W = [padk(g("force_encoder", "0.weight"), fpad).to(wdt).to(dev), g("force_encoder", "0.bias").to(dev),
+             g("force_encoder", "2.weight").to(wdt).to(dev), g("force_encoder", "2.bias").to(dev)]
+        for l in range(layers):
+            wih = g("lstm", f"weight_ih_l{l}")
+            W += [padk(wih, inpad if l == 0 else H).to(wdt).to(dev), g("lstm", f"weight_hh_l{l}").to(wdt).to(dev),
+                  g("lstm", f"bias_ih_l{l}").to(dev), g("lstm", f"bias_hh_l{l}").to(dev)]
+        W += [g("output_head", "0.weight").to(wdt).to(dev), g("output_head", "0.bias").to(dev),
+              g("output_head", "1.weight").to(dev), g("output_head", "1.bias").to(dev),
+              g("output_head", "4.weight").to(wdt).to(dev), g("output_head", "4.bias").to(dev)]
+        W = [w.contiguous() for w in W]
+        self._weights = W
+        desc = L.LstmDesc()
+        desc.state_dim, desc.hidden, desc.layers, desc.force_dim, desc.force_pad, desc.in_pad, desc.cdt = \
+            state_dim, H, layers, force_dim, fpad, inpad, cdt
+        lib = L.lib()
+        assert lib.vt_lstm_num_weights(C.byref(desc)) == len(W)
+        self._h = C.c_void_p()
+        L.check(lib.vt_lstm_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_lstm_create")
+        self._ws = _Workspace(dev)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().vt_lstm_destroy(self._h)
+        except Exception:
+            pass
+
+    def step(self, obs_cond, vla_n, force, h, c) -> torch.Tensor:
+        """One tick; h, c [layers,B,H] fp32 are updated in place; returns normalised vla_n + delta."""
+        dev = self.device
+        B = vla_n.shape[0]
+        obs_cond = obs_cond.to(dev, torch.float32).contiguous()
+        vla_n = vla_n.to(dev, torch.float32).contiguous()
+        force = force.to(dev, torch.float32).contiguous()
+        assert h.is_contiguous() and c.is_contiguous() and h.dtype == torch.float32
+        out = torch.empty(B, self.state_dim, dtype=torch.float32, device=dev)
+        lib = L.lib()
+        ws = self._ws.get(lib.vt_lstm_workspace_bytes(self._h, B))
+        L.check(lib.vt_lstm_step(self._h, L.ptr(obs_cond), L.ptr(vla_n), L.ptr(force), L.ptr(h), L.ptr(c), L.ptr(out), B, L.ptr(ws),
+                                 L.stream_ptr(dev)), "vt_lstm_step")
+        return out

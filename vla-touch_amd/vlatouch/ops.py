@@ -1,0 +1,130 @@
+"""Thin tensor-level wrappers over the primitive C-ABI entries (vt_gemm, vt_attention, vt_groupnorm,
+vt_rownorm).  Used by the parity tests and by host code that composes primitives directly."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+
+def _es(t: torch.Tensor) -> int:
+    return t.element_size()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
+         colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1) -> torch.Tensor:
+    """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N]."""
+    assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    out_dtype = out_dtype or (torch.float32 if splitk > 1 else a.dtype)
+    if out is None:
+        out = torch.empty((splitk, M, N) if splitk > 1 else (M, N), dtype=out_dtype, device=a.device)
+    p = L.GemmParams()
+    p.A, p.W, p.C = a.data_ptr(), w.data_ptr(), out.data_ptr()
+    p.M, p.N, p.K = M, N, K
+    p.lda, p.ldw, p.ldc = a.stride(0), w.stride(0), N
+    p.bias = 0 if bias is None else bias.data_ptr()
+    p.colscale = 0 if colscale is None else colscale.data_ptr()
+    if residual is not None:
+        assert residual.dtype == out_dtype
+        p.residual, p.ldr = residual.data_ptr(), residual.stride(0)
+    p.act, p.groups, p.splitk = act, 1, splitk
+    p.c_slab = M * N
+    p.a_dtype, p.w_dtype, p.c_dtype = L.dt_code(a.dtype), L.dt_code(w.dtype), L.dt_code(out_dtype)
+    L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
+    return out
+
+
+def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], *, taps: int, cin: int, tout: int,
+              stride: int = 1, off0: int = 0, tstep: int = 1, out_dtype: Optional[torch.dtype] = None, splitk: int = 1) -> torch.Tensor:
+    """Channel-last implicit-GEMM conv: x [B, Tin, cin] , w_packed [Cout, taps*cin] -> [B, tout, Cout]."""
+    B, tin, c = x.shape
+    assert c == cin and x.is_contiguous()
+    N = w_packed.shape[0]
+    out_dtype = out_dtype or (torch.float32 if splitk > 1 else x.dtype)
+    out = torch.empty((splitk, B, tout, N) if splitk > 1 else (B, tout, N), dtype=out_dtype, device=x.device)
+    p = L.GemmParams()
+    p.A, p.W, p.C = x.data_ptr(), w_packed.data_ptr(), out.data_ptr()
+    p.M, p.N, p.K = B * tout, N, taps * cin
+    p.lda, p.ldw, p.ldc = cin, taps * cin, N
+    p.taps, p.cin, p.tout, p.tin, p.stride, p.off0, p.tstep = taps, cin, tout, tin, stride, off0, tstep
+    p.bias = 0 if bias is None else bias.data_ptr()
+    p.groups, p.splitk = 1, splitk
+    p.c_slab = B * tout * N
+    p.a_dtype, p.w_dtype, p.c_dtype = L.dt_code(x.dtype), L.dt_code(w_packed.dtype), L.dt_code(out_dtype)
+    L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(x.device)), "vt_gemm(conv)")
+    return out
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
+              kmask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B,Nq,H,64], k/v [B,Nk,H,64] (any strides with unit inner stride) -> [B,Nq,H*64].  kmask [B,Nk] bool."""
+    B, Nq, H, hd = q.shape
+    Nk = k.shape[1]
+    assert hd == 64 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    o = torch.empty(B, Nq, H * 64, dtype=q.dtype, device=q.device)
+    p = L.AttnParams()
+    p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
+    p.q_bs, p.q_rs, p.q_hs = q.stride(0), q.stride(1), q.stride(2)
+    p.k_bs, p.k_rs, p.k_hs = k.stride(0), k.stride(1), k.stride(2)
+    p.v_bs, p.v_rs, p.v_hs = v.stride(0), v.stride(1), v.stride(2)
+    p.o_bs, p.o_rs = Nq * H * 64, H * 64
+    km = None
+    if kmask is not None:
+        km = kmask.to(torch.uint8).contiguous()
+        p.kmask, p.km_bs = km.data_ptr(), Nk
+    p.B, p.H, p.Nq, p.Nk = B, H, Nq, Nk
+    p.scale = scale if scale is not None else 64 ** -0.5
+    p.dtype = L.dt_code(q.dtype)
+    L.check(L.lib().vt_attention(C.byref(p), L.stream_ptr(q.device)), "vt_attention")
+    return o
+
+
+def rownorm(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], eps: float, mode: int = L.NORM_LAYER,
+            out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    assert x.dim() == 2 and x.stride(1) == 1
+    out_dtype = out_dtype or x.dtype
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    L.check(L.lib().vt_rownorm(L.ptr(x), L.dt_code(x.dtype), x.stride(0), L.ptr(y), L.dt_code(out_dtype), y.stride(0), L.ptr(w), L.ptr(b),
+                               x.shape[0], x.shape[1], eps, mode, L.stream_ptr(x.device)), "vt_rownorm")
+    return y
+
+
+def headnorm_(x: torch.Tensor, heads: int, w: torch.Tensor, eps: float = 1e-6, mode: int = L.NORM_RMS_MEANSQ, tok_stride: Optional[int] = None,
+              tokens: Optional[int] = None) -> None:
+    """In-place per-head RMSNorm over 64-wide head slices of a [tokens, >=heads*64] buffer (q_norm / k_norm)."""
+    tok_stride = tok_stride if tok_stride is not None else x.stride(-2)
+    tokens = tokens if tokens is not None else x.numel() // x.shape[-1]
+    L.check(L.lib().vt_headnorm(L.ptr(x), L.dt_code(x.dtype), tok_stride, heads, tokens, L.ptr(w), eps, mode, L.stream_ptr(x.device)), "vt_headnorm")
+
+
+def groupnorm_cl(slabs: torch.Tensor, bias, gamma, beta, *, B: int, T: int, ngroups: int = 8, film: Optional[torch.Tensor] = None,
+                 residual: Optional[torch.Tensor] = None, out_dtype: torch.dtype = torch.float32, eps: float = 1e-5) -> torch.Tensor:
+    """slabs [S, B*T, C] fp32 partial sums -> GroupNorm -> Mish -> FiLM(film [B, 2C]) -> + residual [B*T, C]."""
+    S, M, Cc = slabs.shape
+    assert M == B * T
+    out = torch.empty(M, Cc, dtype=out_dtype, device=slabs.device)
+    p = L.GnParams()
+    p.P, p.nslabs, p.slab_stride, p.p_gs, p.ldp = slabs.data_ptr(), S, M * Cc, 0, Cc
+    p.bias = 0 if bias is None else bias.data_ptr()
+    p.gamma, p.beta, p.vec_gs = gamma.data_ptr(), beta.data_ptr(), 0
+    if film is not None:
+        p.film, p.film_ld, p.film_off, p.film_gs = film.data_ptr(), film.stride(0), 0, 0
+    if residual is not None:
+        assert residual.dtype == out_dtype
+        p.residual, p.ldr, p.r_gs = residual.data_ptr(), residual.stride(0), 0
+    p.out, p.ldo, p.o_gs, p.out_dtype = out.data_ptr(), Cc, 0, L.dt_code(out_dtype)
+    p.B, p.T, p.C, p.ngroups, p.nets, p.eps = B, T, Cc, ngroups, 1, eps
+    L.check(L.lib().vt_groupnorm(C.byref(p), L.stream_ptr(slabs.device)), "vt_groupnorm")
+    return out
+
+
+def mfma_selftest(device="cuda"):
+    err = torch.full((2,), -1.0, dtype=torch.float32, device=device)
+    L.check(L.lib().vt_selftest_mfma(L.ptr(err), L.stream_ptr(err.device)), "vt_selftest_mfma")
+    return err.cpu().tolist()
