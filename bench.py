@@ -190,7 +190,8 @@ def main():
     # ---- CPU baseline: the oracle (fp32 torch on the host cores), rank 0, N=1 only, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "pi_refine":
         from oracle import controller as oc
-        cores = os.cpu_count() or 1
+        # threads actually usable by this process (cgroup/affinity aware): oversubscribing OpenMP stalls in spin barriers
+        cores = min(len(os.sched_getaffinity(0)), torch.get_num_threads())
         torch.set_num_threads(cores)
         cpu = {k: v.cpu() for k, v in inp.items()}
         z = torch.randn(10, B, T, 10)

@@ -145,6 +145,41 @@ size_t vt_lstm_workspace_bytes(vt_lstm_t h, int B);
 int vt_lstm_step(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c,
                  float* out_n, int B, void* workspace, vt_stream_t stream);
 
+/* ---------------------------------------------------------------- RDT diffusion transformer + DPM-Solver++ sampler
+ * Replaces RDT.forward (models/rdt/model.py:126-165; blocks models/rdt/blocks.py:72-202) and
+ * RDTRunner.predict_action / conditional_sample / adapt_conditions (models/rdt_runner.py:108-165, 225-250).
+ * head_dim must be 64; rms_mode as vt_rownorm (1 = mean-square, 2 = timm<=1.0.8 variance form).
+ * Weight order: csrc/vt_rdt.hip header. */
+typedef struct {
+  int hidden, depth, heads, horizon, out_dim;
+  int state_dim;        /* state_token_dim (128); the state adaptor takes 2*state_dim (state | mask) */
+  int lang_dim, img_dim;
+  int max_lang_len, img_len;
+  int n_lang, n_img, n_state;   /* adaptor depths: 1 = 'linear', N = 'mlpNx_gelu' */
+  int cdt, adt;                 /* both fp32 or both bf16 */
+  int rms_mode;
+} vt_rdt_desc;
+int vt_rdt_create(const vt_rdt_desc* desc, const void* const* weights, int n_weights, vt_rdt_t* out);
+void vt_rdt_destroy(vt_rdt_t h);
+int vt_rdt_num_weights(const vt_rdt_desc* desc);
+size_t vt_rdt_workspace_bytes(vt_rdt_t h, int B, int lang_len);
+/* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the
+ * scalar t_host when t_is_scalar, lang_c [B][L][hidden] / img_c [B][img_len][hidden] adt (adapted, before position
+ * embeddings), lang_mask [B][L] bytes (1 = valid) or NULL -> out [B][horizon][out_dim] adt. */
+int vt_rdt_forward(vt_rdt_t h, const void* x_tokens, const float* freq, const float* t_dev, float t_host, int t_is_scalar,
+                   const void* lang_c, const void* img_c, const uint8_t* lang_mask, void* out, int B, int L,
+                   void* workspace, vt_stream_t stream);
+/* RDTRunner.predict_action: lang_tokens [B][L][lang_dim], img_tokens [B][img_len][img_dim], state_tokens [B][1][state_dim],
+ * action_mask [B][1][state_dim] (all adt), ctrl_freqs [B] fp32, x_init [B][horizon][state_dim] fp32 (the N(0,1) start the
+ * reference draws with torch.randn), host arrays timesteps[n_steps] and coef[n_steps][5] = {a, b0, b1, alpha_s, sigma_s} of
+ * the multistep update x <- a x + b0 x0_k + b1 x0_{k-1}; sample_pred: 1 = 'sample' prediction, 0 = 'epsilon'.
+ * adapted != 0 = conditional_sample (rdt_runner.py:122): lang/img/state tokens are already adapted to [.., hidden].
+ * out [B][horizon][state_dim] fp32 (values on the adt grid, masked). */
+int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask, const void* img_tokens,
+                  const void* state_tokens, const void* action_mask, const float* ctrl_freqs, const float* x_init,
+                  int n_steps, const float* timesteps, const float* coef, int sample_pred, int adapted, float* out,
+                  int B, int L, void* workspace, vt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,18 @@ def test_shape_tables_match_reference_modules():
     assert mine == r
     # EMA shadow list order == net.parameters() order == state-dict order (no buffers in the U-Nets)
     assert ref["si_param_order"] == list(synth.si_net_shapes(10, 256).keys())
+
+
+def test_rdt_pos_embed_helpers_match_reference_tables():
+    """The product's sin-cos init tables (vla-touch_amd/models/rdt/blocks.py, numpy on the host) against tables captured
+    from the reference's functions (models/rdt/blocks.py:209-306)."""
+    from collections import OrderedDict
+    from models.rdt.blocks import get_1d_sincos_pos_embed_from_grid, get_multimodal_cond_pos_embed
+    g = G("g8_rdt_fwd")
+    x = get_multimodal_cond_pos_embed(256, OrderedDict([('timestep', 1), ('ctrl_freq', 1), ('state', 1), ('action', 8)]))
+    assert x.shape == g["pos_x"].shape and np.abs(x - g["pos_x"]).max() < 1e-12
+    img = get_multimodal_cond_pos_embed(256, OrderedDict([("image", (2, 3, -4))]), embed_modality=False)
+    assert img.shape == g["pos_img"].shape and np.abs(img - g["pos_img"]).max() < 1e-12
+    lang = get_multimodal_cond_pos_embed(128, OrderedDict([("lang", -5), ("extra", 3)]), embed_modality=True)
+    assert lang.shape == g["pos_lang"].shape and np.abs(lang - g["pos_lang"]).max() < 1e-12
+    assert np.abs(get_1d_sincos_pos_embed_from_grid(64, np.arange(7)) - g["pos_1d"]).max() < 1e-12

@@ -136,7 +136,19 @@ SIGNATURES = {
     "vt_lstm_num_weights": (_I, [_P]),
     "vt_lstm_workspace_bytes": (_Z, [_P, _I]),
     "vt_lstm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "vt_rdt_create": (_I, [_P, _P, _I, _P]),
+    "vt_rdt_destroy": (None, [_P]),
+    "vt_rdt_num_weights": (_I, [_P]),
+    "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "vt_rdt_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
 }
+
+
+class RdtDesc(C.Structure):
+    _fields_ = [("hidden", C.c_int), ("depth", C.c_int), ("heads", C.c_int), ("horizon", C.c_int), ("out_dim", C.c_int),
+                ("state_dim", C.c_int), ("lang_dim", C.c_int), ("img_dim", C.c_int), ("max_lang_len", C.c_int), ("img_len", C.c_int),
+                ("n_lang", C.c_int), ("n_img", C.c_int), ("n_state", C.c_int), ("cdt", C.c_int), ("adt", C.c_int), ("rms_mode", C.c_int)]
 
 
 def check(code: int, what: str = "") -> None:

@@ -1,0 +1,132 @@
+"""RDT engine: packs an RDTRunner state dict (SURVEY Appendix A.5 key layout) and drives vt_rdt_forward /
+vt_rdt_sample.  Weights stay resident in HBM in the execution dtype (bf16 = the reference's dtype, or fp32)."""
+from __future__ import annotations
+
+import ctypes as C
+import re
+from typing import List, Mapping, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dpm
+from .engine import _Workspace
+
+SD = Mapping[str, torch.Tensor]
+
+
+def adaptor_depth(kind: str) -> int:
+    if kind == "linear":
+        return 1
+    m = re.match(r"^mlp(\d+)x_gelu$", kind)
+    if not m:
+        raise ValueError(f"Unknown projector type: {kind}")
+    return int(m.group(1))
+
+
+class RdtEngine:
+    def __init__(self, sd: SD, *, hidden: int, depth: int, heads: int, horizon: int, action_dim: int, lang_token_dim: int,
+                 img_token_dim: int, state_token_dim: int, max_lang_cond_len: int, img_cond_len: int,
+                 lang_adaptor: str = "mlp2x_gelu", img_adaptor: str = "mlp2x_gelu", state_adaptor: str = "mlp3x_gelu",
+                 dtype: torch.dtype = torch.bfloat16, rms_mode: str = "meansq", device="cuda"):
+        self.device = L.require_gpu(device)
+        if hidden // heads != 64:
+            raise L.VtError("RdtEngine: head_dim must be 64")
+        self.dtype = dtype
+        cdt = L.dt_code(dtype)
+        dev = self.device
+        self.cfg = dict(hidden=hidden, depth=depth, heads=heads, horizon=horizon, action_dim=action_dim)
+        self.hidden, self.horizon, self.action_dim, self.img_len, self.max_lang = hidden, horizon, action_dim, img_cond_len, max_lang_cond_len
+        self.state_dim = state_token_dim
+        f32 = torch.float32
+        w = lambda k: sd[k].detach().to(dev, dtype).contiguous()
+        v = lambda k: sd[k].detach().to(dev, f32).contiguous()
+        W: List[torch.Tensor] = []
+        for e in ("t_embedder", "freq_embedder"):
+            W += [w(f"model.{e}.mlp.0.weight"), v(f"model.{e}.mlp.0.bias"), w(f"model.{e}.mlp.2.weight"), v(f"model.{e}.mlp.2.bias")]
+        W += [v("model.x_pos_embed")[0].contiguous(), w("model.lang_cond_pos_embed")[0].contiguous(), w("model.img_cond_pos_embed")[0].contiguous()]
+        for i in range(depth):
+            p = f"model.blocks.{i}"
+            W += [v(f"{p}.norm1.weight"), w(f"{p}.attn.qkv.weight"), v(f"{p}.attn.qkv.bias"), v(f"{p}.attn.q_norm.weight"), v(f"{p}.attn.k_norm.weight"),
+                  w(f"{p}.attn.proj.weight"), v(f"{p}.attn.proj.bias"),
+                  v(f"{p}.norm2.weight"), w(f"{p}.cross_attn.q.weight"), v(f"{p}.cross_attn.q.bias"), w(f"{p}.cross_attn.kv.weight"),
+                  v(f"{p}.cross_attn.kv.bias"), v(f"{p}.cross_attn.q_norm.weight"), v(f"{p}.cross_attn.k_norm.weight"),
+                  w(f"{p}.cross_attn.proj.weight"), v(f"{p}.cross_attn.proj.bias"),
+                  v(f"{p}.norm3.weight"), w(f"{p}.ffn.fc1.weight"), v(f"{p}.ffn.fc1.bias"), w(f"{p}.ffn.fc2.weight"), v(f"{p}.ffn.fc2.bias")]
+        fl = "model.final_layer"
+        W += [v(f"{fl}.norm_final.weight"), w(f"{fl}.ffn_final.fc1.weight"), v(f"{fl}.ffn_final.fc1.bias"), w(f"{fl}.ffn_final.fc2.weight"),
+              v(f"{fl}.ffn_final.fc2.bias")]
+        depths = []
+        for name, kind in (("lang_adaptor", lang_adaptor), ("img_adaptor", img_adaptor), ("state_adaptor", state_adaptor)):
+            n = adaptor_depth(kind)
+            depths.append(n)
+            if n == 1:
+                W += [w(f"{name}.weight"), v(f"{name}.bias")]
+            else:
+                for j in range(n):
+                    W += [w(f"{name}.{2 * j}.weight"), v(f"{name}.{2 * j}.bias")]
+        self._weights = W
+        d = L.RdtDesc()
+        d.hidden, d.depth, d.heads, d.horizon, d.out_dim, d.state_dim = hidden, depth, heads, horizon, action_dim, state_token_dim
+        d.lang_dim, d.img_dim, d.max_lang_len, d.img_len = lang_token_dim, img_token_dim, max_lang_cond_len, img_cond_len
+        d.n_lang, d.n_img, d.n_state = depths
+        d.cdt = d.adt = cdt
+        d.rms_mode = {"meansq": L.NORM_RMS_MEANSQ, "var": L.NORM_RMS_VAR}[rms_mode]
+        lib = L.lib()
+        assert lib.vt_rdt_num_weights(C.byref(d)) == len(W), (lib.vt_rdt_num_weights(C.byref(d)), len(W))
+        self._h = C.c_void_p()
+        L.check(lib.vt_rdt_create(C.byref(d), L.ptr_array(W), len(W), C.byref(self._h)), "vt_rdt_create")
+        self._ws = _Workspace(dev)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().vt_rdt_destroy(self._h)
+        except Exception:
+            pass
+
+    def _ws_for(self, B, Llang):
+        return self._ws.get(L.lib().vt_rdt_workspace_bytes(self._h, B, Llang))
+
+    def forward(self, x, freq, t, lang_c, img_c, lang_mask=None) -> torch.Tensor:
+        """RDT.forward: x [B, horizon+1, D], freq [B], t [B] or [1], lang_c [B,L,D], img_c [B,img_len,D] -> [B, horizon, out]."""
+        dev, dt = self.device, self.dtype
+        B, Llang = x.shape[0], lang_c.shape[1]
+        x = x.to(dev, dt).contiguous()
+        lang_c, img_c = lang_c.to(dev, dt).contiguous(), img_c.to(dev, dt).contiguous()
+        freq = freq.to(dev, torch.float32).contiguous()
+        t = torch.as_tensor(t).to(torch.float32).reshape(-1)
+        scalar = t.numel() == 1
+        tdev = None if scalar else t.to(dev).contiguous()
+        mask = None if lang_mask is None else lang_mask.to(dev).to(torch.uint8).contiguous()
+        out = torch.empty(B, self.horizon, self.action_dim, dtype=dt, device=dev)
+        L.check(L.lib().vt_rdt_forward(self._h, L.ptr(x), L.ptr(freq), L.ptr(tdev), float(t[0]) if scalar else 0.0, int(scalar), L.ptr(lang_c),
+                                       L.ptr(img_c), L.ptr(mask), L.ptr(out), B, Llang, L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)),
+                "vt_rdt_forward")
+        return out
+
+    def sample(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init, *, num_inference_steps: int,
+               num_train_timesteps: int = 1000, beta_schedule: str = "squaredcos_cap_v2", prediction_type: str = "sample",
+               adapted: bool = False) -> torch.Tensor:
+        """RDTRunner.predict_action (adapted=False: raw encoder tokens) / conditional_sample (adapted=True: tokens already
+        projected to hidden size); x_init = the N(0,1) start [B, horizon, action_dim]."""
+        if prediction_type not in ("sample", "epsilon"):
+            raise ValueError(f"Unsupported prediction type {prediction_type}")
+        dev, dt = self.device, self.dtype
+        B, Llang = lang_tokens.shape[0], lang_tokens.shape[1]
+        ts, coef = dpm.schedule(num_train_timesteps, beta_schedule, num_inference_steps)
+        ts_c = (C.c_float * len(ts))(*[float(t) for t in ts])
+        coef_c = (C.c_float * coef.size)(*coef.reshape(-1).tolist())
+        lang_tokens = lang_tokens.to(dev, dt).contiguous()
+        img_tokens = img_tokens.to(dev, dt).contiguous()
+        state_tokens = state_tokens.to(dev, dt).contiguous()
+        action_mask = action_mask.to(dev, dt).contiguous()
+        ctrl_freqs = ctrl_freqs.to(dev, torch.float32).contiguous()
+        x_init = x_init.to(dev, torch.float32).contiguous()
+        mask = lang_attn_mask.to(dev).to(torch.uint8).contiguous()
+        out = torch.empty(B, self.horizon, self.action_dim, dtype=torch.float32, device=dev)
+        L.check(L.lib().vt_rdt_sample(self._h, L.ptr(lang_tokens), L.ptr(mask), L.ptr(img_tokens), L.ptr(state_tokens), L.ptr(action_mask),
+                                      L.ptr(ctrl_freqs), L.ptr(x_init), len(ts), ts_c, coef_c, int(prediction_type == "sample"), int(adapted), L.ptr(out), B, Llang,
+                                      L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)), "vt_rdt_sample")
+        return out.to(dt)
