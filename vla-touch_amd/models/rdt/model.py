@@ -23,7 +23,7 @@ class RDT(ParamModule):
 
     def __init__(self, output_dim=128, horizon=32, hidden_size=1152, depth=28, num_heads=16, max_lang_cond_len=1024,
                  img_cond_len=4096, lang_pos_embed_config=None, img_pos_embed_config=None, dtype=torch.bfloat16,
-                 rms_mode: str = "meansq"):
+                 rms_mode: str = "meansq", init_weights: bool = True):
         self.output_dim, self.horizon, self.hidden_size, self.depth, self.num_heads = output_dim, horizon, hidden_size, depth, num_heads
         self.max_lang_cond_len, self.img_cond_len = max_lang_cond_len, img_cond_len
         self.dtype = dtype
@@ -33,8 +33,9 @@ class RDT(ParamModule):
                                          lang_token_dim=16, img_token_dim=16, state_token_dim=output_dim,
                                          max_lang_cond_len=max_lang_cond_len, img_cond_len=img_cond_len)
         shapes = OrderedDict((k[len("model."):], v) for k, v in shapes.items() if k.startswith("model."))
-        super().__init__(shapes, device="cpu", seed=11)
-        self.initialize_weights()
+        super().__init__(shapes, device="cpu", seed=11, materialize=init_weights)
+        if init_weights:
+            self.initialize_weights()
         self._engine = None
         self._engine_version = -1
 

@@ -30,7 +30,7 @@ from models.rdt.model import RDT
 class _Adaptor(ParamModule):
     """nn.Linear ('weight', 'bias') or nn.Sequential of Linear / GELU(tanh) ('0.weight', '2.weight', ...)."""
 
-    def __init__(self, projector_type, in_features, out_features, seed):
+    def __init__(self, projector_type, in_features, out_features, seed, materialize=True):
         self.projector_type = projector_type
         n = adaptor_depth(projector_type)
         shapes = OrderedDict()
@@ -41,22 +41,23 @@ class _Adaptor(ParamModule):
             for j in range(n):
                 shapes[f"{2 * j}.weight"] = (out_features, in_features if j == 0 else out_features)
                 shapes[f"{2 * j}.bias"] = (out_features,)
-        super().__init__(shapes, device="cpu", seed=seed)
+        super().__init__(shapes, device="cpu", seed=seed, materialize=materialize)
 
 
 class RDTRunner:
     def __init__(self, *, action_dim, pred_horizon, config, lang_token_dim, img_token_dim, state_token_dim, max_lang_cond_len,
                  img_cond_len, lang_pos_embed_config=None, img_pos_embed_config=None, dtype=torch.bfloat16, device="cuda",
-                 rms_mode: Optional[str] = None):
+                 rms_mode: Optional[str] = None, init_weights: bool = True):
         hidden_size = config['rdt']['hidden_size']
         self.config = config
         self.dtype = dtype
         self.device = device
         self.rms_mode = rms_mode or os.environ.get("VLATOUCH_TIMM_RMSNORM", "meansq")
+        self._init_weights = init_weights     # False: shapes only, weights arrive via load_state_dict(..., assign=True)
         self.model = RDT(output_dim=action_dim, horizon=pred_horizon, hidden_size=hidden_size, depth=config['rdt']['depth'],
                          num_heads=config['rdt']['num_heads'], max_lang_cond_len=max_lang_cond_len, img_cond_len=img_cond_len,
                          lang_pos_embed_config=lang_pos_embed_config, img_pos_embed_config=img_pos_embed_config, dtype=dtype,
-                         rms_mode=self.rms_mode)
+                         rms_mode=self.rms_mode, init_weights=init_weights)
         self.lang_adaptor = self.build_condition_adapter(config['lang_adaptor'], in_features=lang_token_dim, out_features=hidden_size)
         self.img_adaptor = self.build_condition_adapter(config['img_adaptor'], in_features=img_token_dim, out_features=hidden_size)
         self.state_adaptor = self.build_condition_adapter(config['state_adaptor'], in_features=state_token_dim * 2, out_features=hidden_size)
@@ -78,7 +79,8 @@ class RDTRunner:
     def build_condition_adapter(self, projector_type, in_features, out_features):
         if projector_type != 'linear' and not re.match(r'^mlp(\d+)x_gelu$', projector_type):
             raise ValueError(f'Unknown projector type: {projector_type}')
-        return _Adaptor(projector_type, in_features, out_features, seed=len(projector_type) + in_features)
+        return _Adaptor(projector_type, in_features, out_features, seed=len(projector_type) + in_features,
+                        materialize=getattr(self, "_init_weights", True))
 
     def state_dict(self):
         sd = OrderedDict()
@@ -87,10 +89,10 @@ class RDTRunner:
                 sd[f"{part}.{k}"] = v
         return sd
 
-    def load_state_dict(self, sd, strict=True):
+    def load_state_dict(self, sd, strict=True, assign=False):
         for part in self._PARTS:
             sub = {k[len(part) + 1:]: v for k, v in sd.items() if k.startswith(part + ".")}
-            getattr(self, part).load_state_dict(sub, strict=strict)
+            getattr(self, part).load_state_dict(sub, strict=strict, assign=assign)
         extra = [k for k in sd if k.split(".")[0] not in self._PARTS]
         if strict and extra:
             raise RuntimeError(f"unexpected keys in state_dict: {extra[:5]}")

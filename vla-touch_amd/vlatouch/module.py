@@ -38,11 +38,14 @@ def _init_tensor(key: str, shape: Sequence[int], gen: torch.Generator) -> torch.
 
 
 class ParamModule:
-    def __init__(self, shapes: Mapping[str, Sequence[int]], device="cpu", seed: int = 0):
+    def __init__(self, shapes: Mapping[str, Sequence[int]], device="cpu", seed: int = 0, materialize: bool = True):
+        """`materialize=False` records the shapes only (zero-size placeholders): for billion-parameter models whose weights
+        arrive through load_state_dict(..., assign=True)."""
         gen = torch.Generator().manual_seed(seed)
         self._params: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self._shapes = OrderedDict((k, tuple(int(x) for x in s)) for k, s in shapes.items())
         for k, s in shapes.items():
-            self._params[k] = _init_tensor(k, s, gen).to(device)
+            self._params[k] = _init_tensor(k, s, gen).to(device) if materialize else torch.empty(0)
         self.training = False
         self.version = 0
 
@@ -50,7 +53,9 @@ class ParamModule:
     def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
         return OrderedDict((k, v) for k, v in self._params.items())
 
-    def load_state_dict(self, sd: Mapping[str, torch.Tensor], strict: bool = True):
+    def load_state_dict(self, sd: Mapping[str, torch.Tensor], strict: bool = True, assign: bool = False):
+        """`assign=True` (torch's keyword) adopts the given tensors as they are (device and dtype preserved, no copy) —
+        used to load multi-GB weights that already live in HBM in their execution dtype."""
         missing = [k for k in self._params if k not in sd]
         unexpected = [k for k in sd if k not in self._params]
         if strict and (missing or unexpected):
@@ -59,9 +64,9 @@ class ParamModule:
         for k in self._params:
             if k in sd:
                 t = torch.as_tensor(sd[k])
-                if tuple(t.shape) != tuple(self._params[k].shape):
-                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {tuple(self._params[k].shape)}")
-                self._params[k] = t.detach().to(self._params[k].device, torch.float32).clone()
+                if tuple(t.shape) != self._shapes[k]:
+                    raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(t.shape)} vs model {self._shapes[k]}")
+                self._params[k] = t.detach() if assign else t.detach().to(self._params[k].device, torch.float32).clone()
         self.version += 1
         return self
 

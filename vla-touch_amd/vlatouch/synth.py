@@ -50,6 +50,29 @@ def fill_state_dict(shapes: Mapping[str, Sequence[int]], prefix: str = "", salt:
     return {k: tensor(prefix + k, s, salt) for k, s in shapes.items()}
 
 
+def fill_state_dict_device(shapes: Mapping[str, Sequence[int]], device, dtype, seed: int = 0):
+    """Same scale rules as `tensor`, drawn with the DEVICE generator straight into HBM in `dtype` — for billion-parameter
+    random-init models (bench.py's RDT-1B), where a host-side numpy fill + upload would take minutes.  Not bit-identical to
+    `tensor` (different generator); used only where no golden vector depends on the values."""
+    import torch
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(s) for s in shape)
+        z = torch.randn(shape, generator=g, device=device, dtype=torch.float32)
+        leaf = name.split(".")[-1]
+        if any(k in name for k in ("pos_embed", "position_embeddings", "cls_token", "mask_token")):
+            z.mul_(0.2)
+        elif len(shape) >= 2:
+            z.mul_(1.0 / float(np.sqrt(max(int(np.prod(shape[1:])), 1))))
+        elif leaf in ("weight", "lambda1"):
+            z.mul_(0.1).add_(1.0)
+        else:
+            z.mul_(0.1)
+        out[name] = z.to(dtype)
+    return out
+
+
 def inputs_rng(seed: int = 1234) -> np.random.Generator:
     """synthetic inputs come from numpy PCG64(seed)."""
     return np.random.Generator(np.random.PCG64(seed))
