@@ -178,3 +178,31 @@ def test_action_normalize_matches_golden(dev):
         assert np.abs(out.cpu().numpy() - g[key]).max() < 2e-6
         out = action_normalize(a, mn, mx, denorm=True)
         assert np.abs(out.cpu().numpy() - g["d_" + key[2:]]).max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(2144, 6144, 2048), (4374, 4096, 2048), (1000, 768, 3072)])
+def test_gemm_large_path_with_fused_headnorm(dev, M, N, K):
+    """The LDS-DMA large-GEMM kernel incl. its fused per-head RMSNorm epilogue (q_norm | k_norm | v untouched)."""
+    from vlatouch import ops, _lib as L
+    a = rnd((M, K), 1, dev, torch.bfloat16)
+    w = rnd((N, K), 2, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    w0, w1 = rnd((64,), 4, dev) + 1, rnd((64,), 5, dev) + 1
+    y = a.float() @ w.float().t() + bias
+    plain = ops.gemm(a, w, bias, out_dtype=torch.float32)
+    assert rel_err(plain, y) < 2e-3
+    if ((M + 127) // 128) * ((N + 127) // 128) < 96:      # too few tiles for the large-GEMM path: no fused head-norm there
+        with pytest.raises(L.VtError):
+            ops.gemm(a, w, bias, out_dtype=torch.float32, headnorm=(w0, 64, None, 64, 1e-6, L.NORM_RMS_MEANSQ))
+        return
+    c0, c1 = (N // 3 // 64) * 64, 2 * (N // 3 // 64) * 64
+    for mode in (L.NORM_RMS_MEANSQ, L.NORM_RMS_VAR):
+        ref = y.clone().reshape(M, N // 64, 64)
+        h0, h1 = c0 // 64, c1 // 64
+        var = (lambda t: t.pow(2).mean(-1, keepdim=True)) if mode == L.NORM_RMS_MEANSQ else (lambda t: t.var(-1, keepdim=True))
+        ref[:, :h0] = ref[:, :h0] * torch.rsqrt(var(ref[:, :h0]) + 1e-6) * w0
+        ref[:, h0:h1] = ref[:, h0:h1] * torch.rsqrt(var(ref[:, h0:h1]) + 1e-6) * w1
+        out = ops.gemm(a, w, bias, out_dtype=torch.float32, headnorm=(w0, c0, w1, c1, 1e-6, mode))
+        assert rel_err(out, ref.reshape(M, N)) < 3e-3, mode
+        outb = ops.gemm(a, w, bias, out_dtype=torch.bfloat16, headnorm=(w0, c0, w1, c1, 1e-6, mode))
+        assert rel_err(outb.float(), ref.reshape(M, N)) < 1e-2

@@ -137,3 +137,22 @@ def test_conditional_sample_equals_predict_action_and_errors():
     with pytest.raises(ValueError):
         r.predict_action(ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"])
     r.prediction_type = "sample"
+
+
+def test_rdt_wide_batch_takes_large_gemm_path_with_fused_headnorm():
+    """D=2048, B=4 (M = 268 rows): the GEMMs run on the LDS-DMA kernel with q/k RMSNorm fused in the epilogue."""
+    from oracle import rdt as orr
+    cfg = cases.RDT_WIDE
+    g = G("g8_rdt_fwd")
+    m = make_rdt(cfg, torch.bfloat16)
+    ri = cases.rdt_inputs(cfg, 4, 20, seed=9, dtype=torch.bfloat16)
+    y = m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"])
+    sd = cases.rdt_sd(cfg, torch.bfloat16)
+    f32 = {k: v.float() for k, v in sd.items()}
+    rf = {k: (v.float() if v.is_floating_point() else v) for k, v in ri.items()}
+    exact = orr.rdt_forward(f32, rf["x"], rf["freq"], rf["t"], rf["lang_c"], rf["img_c"], lang_mask=rf["lang_mask"], heads=cfg["heads"], horizon=cfg["horizon"])
+    ref16 = orr.rdt_forward(sd, ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"], heads=cfg["heads"], horizon=cfg["horizon"])
+    scale = float(exact.abs().max())
+    e_hip, e_ref = err(y, exact.numpy()), err(ref16.float(), exact.numpy())
+    print(f"[wide B4] scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |ref16-exact| {e_ref:.3e}")
+    assert e_hip <= max(1e-2 * scale, 1.5 * e_ref), (e_hip, e_ref)

@@ -54,8 +54,11 @@ template <> struct VtRead<float> {
   }
 };
 
+// blockDim.x = 64 * NW (NW = 4..8 waves); a block owns 16*NW query rows of one (batch, head); NW is chosen by the host
+// to minimise padded query rows (e.g. 5 waves = 80 rows for RDT's 67 queries, so its 4 374-key cross-attention streams
+// K/V once per (batch, head) instead of twice).
 template <typename T>
-__global__ __launch_bounds__(256) void attn_kernel(const VtAttnParams p) {
+__global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
   constexpr int HD = 64, KT = 64;
   constexpr int ES = sizeof(T);
   constexpr int EPC = Elem<T>::EPC;
@@ -70,7 +73,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const VtAttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 64 + wave * 16 + l15;
+  const int nthreads = blockDim.x;
+  const int q = blockIdx.x * (nthreads >> 2) + wave * 16 + l15;
   const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
   const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
   const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
@@ -90,9 +94,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const VtAttnParams p) {
     const int key0 = tile * KT;
     __syncthreads();   // previous tile fully consumed
     // ---- stage K (row-major, swizzled) and V (transposed)
-#pragma unroll
-    for (int i = 0; i < (KT * CPK) / 256; ++i) {
-      const int ci = i * 256 + tid;
+    for (int ci = tid; ci < KT * CPK; ci += nthreads) {
       const int key = ci / CPK, cidx = ci - key * CPK;
       const bool ok = key0 + key < p.Nk;
       uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
@@ -187,8 +189,14 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
   const int epc = p.dtype == VT_BF16 ? 8 : 4;
   if (p.q_rs % epc || p.k_rs % epc || p.v_rs % epc || p.q_hs % epc || p.k_hs % epc || p.v_hs % epc) return VT_ERR_ARG;
-  dim3 grid((p.Nq + 63) / 64, p.H, p.B);
-  if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(256), 0, s, p);
+  int nw = 4, best = 1 << 30;
+  for (int w = 4; w <= 8; ++w) {                      // fewest padded query rows; ties -> fewer waves
+    const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
+    if (padded < best) { best = padded; nw = w; }
+  }
+  const int rows = nw * 16;
+  dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
+  if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(64 * nw), 0, s, p);
+  else hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(64 * nw), 0, s, p);
   return vt_check_launch();
 }

@@ -22,4 +22,9 @@ struct VtGemmParams {
   long a_gs, w_gs, c_gs, bias_gs, r_gs;   // per-group element strides
   long c_slab;                            // per-slice element stride of the fp32 partial slabs
   int a_dtype, w_dtype, c_dtype;          // VT_F32 / VT_BF16 (residual has c_dtype)
+  // fused per-head (64 columns) RMSNorm after the bias — timm Attention q_norm / k_norm (large-GEMM path only):
+  // columns [0, hn_c0_end) use gains hn_w0[64], columns [hn_c0_end, hn_c1_end) use hn_w1[64]; mode 1 mean-square, 2 variance.
+  const float* hn_w0; const float* hn_w1;
+  int hn_c0_end, hn_c1_end;
+  float hn_eps; int hn_mode;
 };

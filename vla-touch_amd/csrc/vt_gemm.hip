@@ -9,6 +9,9 @@
 // the epilogue reads bias/colscale/residual and writes C with 16-B (f32) / 8-B (bf16) vectors.
 #include "vt_common.h"
 #include "vt_gemm.h"
+#include "vt_prof.h"
+
+VtProfState g_vt_prof;
 
 namespace {
 
@@ -275,30 +278,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
   }
 }
 
-// ---- live per-kernel timing of the dominant (128x128-tile bf16) GEMM class: HIP events recorded on the launch
-// stream around every launch of that kernel while profiling is enabled (bench.py's roofline leg).
-struct ProfState {
-  bool on = false;
-  static constexpr int MAXEV = 4096;
-  hipEvent_t ev[2 * MAXEV];
-  int created = 0, used = 0;
-  double flops = 0.0, bytes = 0.0;
-} g_prof;
-
-struct ProfScope {
-  bool active; hipStream_t s; int idx;
-  ProfScope(bool want, const VtGemmParams& p, hipStream_t st) : active(want && g_prof.on && g_prof.used < ProfState::MAXEV), s(st), idx(0) {
-    if (!active) return;
-    idx = g_prof.used++;
-    while (g_prof.created < 2 * (idx + 1)) hipEventCreate(&g_prof.ev[g_prof.created++]);
-    g_prof.flops += 2.0 * p.M * (double)p.N * p.K * p.groups;
-    const double es = p.w_dtype == VT_BF16 ? 2.0 : 4.0;
-    g_prof.bytes += ((double)p.M * p.K + (double)p.N * p.K) * es * p.groups + (double)p.M * p.N * p.groups * (p.c_dtype == VT_BF16 ? 2.0 : 4.0);
-    hipEventRecord(g_prof.ev[2 * idx], s);
-  }
-  ~ProfScope() { if (active) hipEventRecord(g_prof.ev[2 * idx + 1], s); }
-};
-
 template <typename TA, typename TW, typename TC>
 int launch_cfg(const VtGemmParams& p, hipStream_t s) {
   const int z = p.groups * p.splitk;
@@ -307,7 +286,6 @@ int launch_cfg(const VtGemmParams& p, hipStream_t s) {
   if constexpr (!Cmp<TW>::X3) {
     if (p.M >= 128 && tiles128 >= 192) {
       dim3 grid((p.N + 127) / 128, (p.M + 127) / 128, z);
-      ProfScope prof(sizeof(TA) == 2, p, s);
       hipLaunchKernelGGL((gemm_kernel<TA, TW, TC, 2, 2, 4, 4>), grid, dim3(256), 0, s, p);
       return vt_check_launch();
     }
@@ -333,6 +311,8 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.taps && (p.cin % epc || p.K != p.taps * p.cin)) return VT_ERR_ARG;
   if (p.splitk < 1 || p.groups < 1) return VT_ERR_ARG;
   if (p.splitk > 1 && p.c_dtype != VT_F32) return VT_ERR_ARG;
+  if (vt_gemm_fast_eligible(p)) return vt_gemm_fast_launch(p, s);     // large bf16 GEMMs: LDS-DMA pipeline (vt_gemm_fast.hip)
+  if (p.hn_w0 || p.hn_w1) return VT_ERR_UNSUPPORTED;                   // fused head-norm exists only on the fast path
   if (p.a_dtype == VT_BF16 && p.w_dtype == VT_BF16) {
     return p.c_dtype == VT_BF16 ? launch_cfg<bf16_t, bf16_t, bf16_t>(p, s) : launch_cfg<bf16_t, bf16_t, float>(p, s);
   }
@@ -346,21 +326,21 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
 
 // ---- profiling control (exported through include/vlatouch.h)
 extern "C" int vt_prof_enable(int on) {
-  g_prof.on = on != 0;
-  if (on) { g_prof.used = 0; g_prof.flops = 0.0; g_prof.bytes = 0.0; }
+  g_vt_prof.on = on != 0;
+  if (on) { g_vt_prof.used = 0; g_vt_prof.flops = 0.0; g_vt_prof.bytes = 0.0; }
   return VT_OK;
 }
 // After the stream has been synchronised by the caller: total milliseconds, algorithmic flops and bytes, launch count.
 extern "C" int vt_prof_collect(double* total_ms, double* flops, double* bytes, long* launches) {
   double ms = 0.0;
-  for (int i = 0; i < g_prof.used; ++i) {
+  for (int i = 0; i < g_vt_prof.used; ++i) {
     float t = 0.f;
-    if (hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess) return VT_ERR_LAUNCH;
+    if (hipEventElapsedTime(&t, g_vt_prof.ev[2 * i], g_vt_prof.ev[2 * i + 1]) != hipSuccess) return VT_ERR_LAUNCH;
     ms += t;
   }
   if (total_ms) *total_ms = ms;
-  if (flops) *flops = g_prof.flops;
-  if (bytes) *bytes = g_prof.bytes;
-  if (launches) *launches = g_prof.used;
+  if (flops) *flops = g_vt_prof.flops;
+  if (bytes) *bytes = g_vt_prof.bytes;
+  if (launches) *launches = g_vt_prof.used;
   return VT_OK;
 }

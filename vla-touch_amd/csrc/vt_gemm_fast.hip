@@ -1,0 +1,221 @@
+// vt_gemm_fast.hip — the large-GEMM path: bf16 x bf16 -> fp32 accumulate on v_mfma_f32_16x16x32_bf16, for every big
+// Linear of RDT and DINOv2 (C = epilogue(A[M,K] W[N,K]^T), K % 64 == 0).
+//
+// Structure: BM x 128 x 64 block tile (BM = 128 or 64), 256 threads = 4 waves (2x2), each wave (BM/2) x 64 output =
+// (BM/32) x 4 MFMA tiles.  Operand tiles go HBM/L2 -> LDS by DMA (`global_load_lds_dwordx4`, 16 B per lane, no VGPR
+// round trip): a wave instruction fills 1 KiB = 8 rows x 128 B of the tile; the LDS image is lane-linear, so the XOR
+// chunk swizzle that makes the 16-row fragment reads (ds_read_b128) bank-conflict-free is applied to the SOURCE
+// address of each lane and again on the read (same involution both sides).  Two LDS stages (2 blocks/CU): the DMA of
+// k-tile t+1 is issued before the MFMAs of tile t; one barrier per k-tile.  Blocks are dealt to XCDs in contiguous
+// bands of tiles so neighbouring tiles share operand panels in that XCD's private L2.
+// Operands are swapped (D = W_tile A_tile^T) so a lane ends with 4 consecutive n of one row m.
+// Epilogue: + bias, optional per-head RMSNorm (q_norm / k_norm of timm Attention: a wave's 64 columns are exactly
+// one head, the row's 64 values live in the 4 lanes sharing lane&15 -> two shuffles), activation, column scale
+// (LayerScale); then the wave's sub-tile goes through a private LDS patch and is written (and the residual read) as
+// WHOLE 256-B / 128-B row segments — the MFMA register layout alone would scatter 32-B pieces over 16 rows per store.
+#include <stdlib.h>
+#include "vt_common.h"
+#include "vt_gemm.h"
+#include "vt_prof.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int BN = 128, BK = 64;
+constexpr int EP_LD = 68;                      // floats per row of the epilogue patch (64 + 4 pad, keeps 16-B alignment)
+constexpr int EP_BYTES = 32 * EP_LD * 4;       // per-wave patch: 32 rows x 64 columns fp32
+
+template <typename TC, int BM>
+__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles) {
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int TM = BM / 32;               // 16-row MFMA tiles per wave along M
+  constexpr int QA = BM / 32;               // A-tile DMA instructions per wave
+  static_assert(2 * STAGE_BYTES >= 4 * EP_BYTES, "epilogue patches must fit in the operand stages");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, l15 = lane & 15;
+
+  int bid = blockIdx.x;
+  if ((total_tiles & 7) == 0) bid = (bid & 7) * (total_tiles >> 3) + (bid >> 3);     // XCD b%8 gets a contiguous band
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  const int tm = t_in / tiles_n, tn = t_in - tm * tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)grp * p.a_gs;
+  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + (long)grp * p.w_gs;
+
+  // DMA sources: instruction q of this wave fills 8 LDS rows; lane -> (row, chunk position); it fetches the chunk whose
+  // swizzled position is its own.  Rows beyond M / N are clamped (computed, never stored).
+  const bf16_t* a_src[QA];
+  const bf16_t* b_src[4];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int r = (wave * QA + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    a_src[q] = A + (long)min(m0 + r, p.M - 1) * p.lda + c * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = (wave * 4 + q) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    b_src[q] = W + (long)min(n0 + r, p.N - 1) * p.ldw + c * 8;
+  }
+  auto stage = [&](int buf, int kt) {
+    char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int q = 0; q < QA; ++q)
+      __builtin_amdgcn_global_load_lds((glb_void*)(a_src[q] + (long)kt * BK), (lds_void*)(base + (wave * QA + q) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_global_load_lds((glb_void*)(b_src[q] + (long)kt * BK), (lds_void*)(base + BM * 128 + (wave * 4 + q) * 1024), 16, 0, 0);
+  };
+
+  float4_t acc[4][TM];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  __syncthreads();          // drains the DMA (vmcnt) and publishes stage 0
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const char* As = smem + cur * STAGE_BYTES;
+    const char* Bs = As + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      Frag<bf16_t> af[TM], wf[4];
+#pragma unroll
+      for (int j = 0; j < TM; ++j) lds_frag(af[j], As, wm * (BM / 2) + j * 16 + l15, ks * 4 + g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lds_frag(wf[i], Bs, wn * 64 + i * 16 + l15, ks * 4 + g);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) mma16(acc[i][j], wf[i], af[j]);
+    }
+    __syncthreads();        // next stage landed (vmcnt(0) inside) and everyone is done reading `cur`
+  }
+
+  // ---------------- epilogue.  Register layout: C[m = .. + j*16 + l15][n = ncol0 + i*16 + g*4 + r]
+  const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
+  const float* cs = p.colscale;
+  const int ncol0 = n0 + wn * 64;                      // this wave's 64 columns = one attention head when hn is active
+  const int mrow0 = m0 + wm * (BM / 2);
+  const float* hw = nullptr;
+  if (p.hn_w0 && ncol0 < p.hn_c0_end) hw = p.hn_w0;
+  else if (p.hn_w1 && ncol0 >= p.hn_c0_end && ncol0 < p.hn_c1_end) hw = p.hn_w1;
+  float* ep = reinterpret_cast<float*>(smem + wave * EP_BYTES);      // private patch: no block barrier needed below
+  TC* Cg = reinterpret_cast<TC*>(p.C) + (long)grp * p.c_gs;
+  const TC* Rg = p.residual ? reinterpret_cast<const TC*>(p.residual) + (long)grp * p.r_gs : nullptr;
+#pragma unroll
+  for (int jp = 0; jp < TM; jp += 2) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+      const int j = jp + jj;
+      float v[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int nn = min(ncol0 + i * 16 + g * 4 + r, p.N - 1);
+          v[i][r] = acc[i][j][r] + (bias ? bias[nn] : 0.f);
+        }
+      if (hw) {   // per-head RMSNorm over the 64 columns of this row (wave-uniform branch; all lanes shuffle)
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s += v[i][r]; q += v[i][r] * v[i][r]; }
+        s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+        q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+        float var;
+        if (p.hn_mode == 2) { const float mean = s * (1.f / 64.f); var = (q - 64.f * mean * mean) * (1.f / 63.f); }
+        else var = q * (1.f / 64.f);
+        const float rstd = rsqrtf(var + p.hn_eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[i][r] = v[i][r] * rstd * hw[i * 16 + g * 4 + r];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float4 o;
+        float* op = &o.x;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = act_apply(v[i][r], p.act);
+          if (cs) x *= cs[min(ncol0 + i * 16 + g * 4 + r, p.N - 1)];
+          op[r] = x;
+        }
+        *reinterpret_cast<float4*>(ep + (jj * 16 + l15) * EP_LD + i * 16 + g * 4) = o;
+      }
+    }
+    // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 4 + (lane >> 4), c4 = lane & 15;
+      const float4 x = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);
+      const int m = mrow0 + jp * 16 + row, n = ncol0 + c4 * 4;
+      if (m < p.M && n < p.N) {
+        float o[4] = {x.x, x.y, x.z, x.w};
+        if constexpr (sizeof(TC) == 4) {
+          if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+          *reinterpret_cast<float4*>(Cg + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+          if (Rg) {
+            const uint2 t = *reinterpret_cast<const uint2*>(Rg + (long)m * p.ldr + n);
+            o[0] += __uint_as_float(t.x << 16); o[1] += __uint_as_float(t.x & 0xffff0000u);
+            o[2] += __uint_as_float(t.y << 16); o[3] += __uint_as_float(t.y & 0xffff0000u);
+          }
+          uint2 t;
+          t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+          t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+          *reinterpret_cast<uint2*>(Cg + (long)m * p.ldc + n) = t;
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int g_vt_force_bm = 0;   // tuning hook (VLATOUCH_GEMM_BM=64|128)
+
+bool vt_gemm_fast_eligible(const VtGemmParams& p) {
+  static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); return true; }();
+  (void)init;
+  if (p.a_dtype != VT_BF16 || p.w_dtype != VT_BF16 || p.taps != 0 || p.splitk != 1) return false;
+  if (p.c_dtype != VT_BF16 && p.c_dtype != VT_F32) return false;
+  if (p.K % BK || p.lda % 8 || p.ldw % 8 || p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)) return false;
+  if (p.M < 128) return false;
+  const long tiles = (long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.groups;
+  return tiles >= 96;
+}
+
+bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p) { return vt_gemm_fast_eligible(p) && (p.N % 64) == 0; }
+
+int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const long tiles128 = (long)((p.M + 127) / 128) * tiles_n * p.groups;
+  // 512 block slots on the chip (256 CUs x 2): below ~4 waves of 128-row tiles, halve the tile to fill the machine
+  const int bm = (g_vt_force_bm == 64 || g_vt_force_bm == 128) ? g_vt_force_bm : (tiles128 < 2048 ? 64 : 128);
+  const int tiles_m = (p.M + bm - 1) / bm;
+  const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
+  VtProfScope prof(true, p, s);
+  if (bm == 128) {
+    if (p.c_dtype == VT_BF16) hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, 128>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+    else hipLaunchKernelGGL((gemm_glds_kernel<float, 128>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+  } else {
+    if (p.c_dtype == VT_BF16) hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, 64>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+    else hipLaunchKernelGGL((gemm_glds_kernel<float, 64>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+  }
+  return vt_check_launch();
+}

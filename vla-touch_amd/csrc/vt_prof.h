@@ -1,0 +1,32 @@
+// vt_prof.h — live per-launch timing of the dominant GEMM class (bench.py's roofline leg): while enabled, every launch
+// of the large-tile bf16 GEMM is bracketed by HIP events recorded on its launch stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vt_common.h"
+#include "vt_gemm.h"
+
+struct VtProfState {
+  bool on = false;
+  static constexpr int MAXEV = 8192;
+  hipEvent_t ev[2 * MAXEV];
+  int created = 0, used = 0;
+  double flops = 0.0, bytes = 0.0;
+};
+extern VtProfState g_vt_prof;
+
+struct VtProfScope {
+  bool active; hipStream_t s; int idx;
+  VtProfScope(bool want, const VtGemmParams& p, hipStream_t st) : active(want && g_vt_prof.on && g_vt_prof.used < VtProfState::MAXEV), s(st), idx(0) {
+    if (!active) return;
+    idx = g_vt_prof.used++;
+    while (g_vt_prof.created < 2 * (idx + 1)) (void)hipEventCreate(&g_vt_prof.ev[g_vt_prof.created++]);
+    g_vt_prof.flops += 2.0 * p.M * (double)p.N * p.K * p.groups;
+    g_vt_prof.bytes += ((double)p.M * p.K + (double)p.N * p.K) * 2.0 * p.groups + (double)p.M * p.N * p.groups * (p.c_dtype == VT_BF16 ? 2.0 : 4.0);
+    (void)hipEventRecord(g_vt_prof.ev[2 * idx], s);
+  }
+  ~VtProfScope() { if (active) (void)hipEventRecord(g_vt_prof.ev[2 * idx + 1], s); }
+};
+
+bool vt_gemm_fast_eligible(const VtGemmParams& p);
+bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p);
+int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s);

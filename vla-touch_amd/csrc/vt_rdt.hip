@@ -24,6 +24,7 @@
 #include "vt_common.h"
 #include "vt_kernels.h"
 #include "vt_host.h"
+#include "vt_prof.h"
 #include "../../include/vlatouch.h"
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
@@ -126,6 +127,13 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
 
 struct RCtx { const vt_rdt_s* h; int B, L; char* ws; RWs w; hipStream_t s; int a; };
 
+// request the fused per-head RMSNorm epilogue when this GEMM takes the large-GEMM path; returns false -> caller runs vt_k_headnorm
+bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1, int c1_end, int mode) {
+  if (!vt_gemm_can_fuse_headnorm(p)) return false;
+  p.hn_w0 = w0; p.hn_c0_end = c0_end; p.hn_w1 = w1; p.hn_c1_end = c1_end; p.hn_eps = 1e-6f; p.hn_mode = mode;
+  return true;
+}
+
 // adaptor MLP: Linear (gelu_tanh Linear)*  — final layer writes `dst` (ld = D) with optional per-row-in-sample residual (pos embed)
 int run_adaptor(RCtx& c, const Adaptor& ad, const void* in, long rows_per_sample, int samples, void* dst, const void* pos, char* tA, char* tB) {
   const vt_rdt_desc& d = c.h->d;
@@ -182,8 +190,9 @@ int cache_cond(RCtx& c) {
     char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
     const void* src = lang ? c.ws + c.w.lang_c : c.ws + c.w.img_c;
     VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
+    const bool fused = fuse_headnorm(p, b.ckn, D, nullptr, D, d.rms_mode);     // k_norm on the K half, in the GEMM epilogue
     CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cond kv"));
-    CK(vt_k_headnorm(kv, d.adt, 2 * D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
+    if (!fused) CK(vt_k_headnorm(kv, d.adt, 2 * D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
   }
   return VT_OK;
 }
@@ -198,9 +207,12 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     // --- self attention
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt qkv")); }
-    CK(vt_k_headnorm(c.ws + c.w.qkv, d.adt, 3 * D, d.heads, M, b.qn, 1e-6f, d.rms_mode, c.s));
-    CK(vt_k_headnorm(c.ws + c.w.qkv + (size_t)D * a, d.adt, 3 * D, d.heads, M, b.kn, 1e-6f, d.rms_mode, c.s));
+      const bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
+      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt qkv"));
+      if (!fused) {
+        CK(vt_k_headnorm(c.ws + c.w.qkv, d.adt, 3 * D, d.heads, M, b.qn, 1e-6f, d.rms_mode, c.s));
+        CK(vt_k_headnorm(c.ws + c.w.qkv + (size_t)D * a, d.adt, 3 * D, d.heads, M, b.kn, 1e-6f, d.rms_mode, c.s));
+      } }
     CK(attn(c, c.ws + c.w.qkv, 3 * D, c.ws + c.w.qkv + (size_t)D * a, c.ws + c.w.qkv + (size_t)2 * D * a, 3 * D, N, N, nullptr, c.ws + c.w.att));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
@@ -211,8 +223,9 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     const char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross q")); }
-    CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s));
+      const bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
+      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross q"));
+      if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
     CK(attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;

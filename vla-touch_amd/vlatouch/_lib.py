@@ -38,6 +38,8 @@ class GemmParams(C.Structure):
         ("a_gs", C.c_long), ("w_gs", C.c_long), ("c_gs", C.c_long), ("bias_gs", C.c_long), ("r_gs", C.c_long),
         ("c_slab", C.c_long),
         ("a_dtype", C.c_int), ("w_dtype", C.c_int), ("c_dtype", C.c_int),
+        ("hn_w0", C.c_void_p), ("hn_w1", C.c_void_p), ("hn_c0_end", C.c_int), ("hn_c1_end", C.c_int),
+        ("hn_eps", C.c_float), ("hn_mode", C.c_int),
     ]
 
 

@@ -16,8 +16,10 @@ def _es(t: torch.Tensor) -> int:
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
          colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
-         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1) -> torch.Tensor:
-    """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N]."""
+         out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1,
+         headnorm=None) -> torch.Tensor:
+    """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
+    headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only)."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
@@ -36,6 +38,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     p.act, p.groups, p.splitk = act, 1, splitk
     p.c_slab = M * N
     p.a_dtype, p.w_dtype, p.c_dtype = L.dt_code(a.dtype), L.dt_code(w.dtype), L.dt_code(out_dtype)
+    if headnorm is not None:
+        w0, c0, w1, c1, eps, mode = headnorm
+        p.hn_w0, p.hn_c0_end = w0.data_ptr(), c0
+        p.hn_w1, p.hn_c1_end = (0 if w1 is None else w1.data_ptr()), c1
+        p.hn_eps, p.hn_mode = eps, mode
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
     return out
 
