@@ -29,6 +29,19 @@ struct VtAttnParams {
   int dtype;
 };
 
+// cross-attention against the cached condition: K [B][Nk][k_rs] (+h*64), Vt [B][H][64][Lpad] (bf16 only)
+struct VtAttnKvtParams {
+  const void* Q; const void* K; const void* VT; void* O;
+  long q_bs, q_rs;            // Q element strides: batch, row (head h at +h*64)
+  long k_bs, k_rs;
+  long o_bs, o_rs;
+  const uint8_t* kmask;       // [B][Nk] or null
+  int B, H, Nq, Nk, Lpad;
+  float scale;
+};
+int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s);
+int vt_k_transpose_v(const void* V, long ld, void* VT, int B, int L, int Lpad, int H, hipStream_t s);
+
 int vt_gemm_launch(const VtGemmParams& p, hipStream_t s);
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s);
 

@@ -93,6 +93,7 @@ int vt_rdt_create(const vt_rdt_desc* desc, const void* const* w, int n, vt_rdt_t
 void vt_rdt_destroy(vt_rdt_t h) { delete h; }
 
 namespace {
+inline int lpad64(int L) { return (L + 63) / 64 * 64; }
 struct RWs {
   size_t lang_c, img_c, tmpA, tmpB, state_tok, freq_emb, t_emb, emb_tmp, sin, kv_lang, kv_img, x, xn, qkv, q, att, hid, sa_in, sa_tmpA, sa_tmpB,
       out_tok, x0_cur, x0_prev, noisy, noisy_a, total;
@@ -110,8 +111,9 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.state_tok = take((size_t)B * D * a); w.freq_emb = take((size_t)B * D * a); w.t_emb = take((size_t)B * D * a);
   w.emb_tmp = take((size_t)B * D * a); w.sin = take((size_t)B * 256 * a);
   const int n_lang_blk = (d.depth + 1) / 2, n_img_blk = d.depth / 2;
-  w.kv_lang_blk = ((size_t)B * L * 2 * D * a + 255) / 256 * 256;
-  w.kv_img_blk = ((size_t)B * Li * 2 * D * a + 255) / 256 * 256;
+  // per block: fp32 mode [B*L][2D] (K | V interleaved per token); bf16 mode K [B*L][D] followed by Vt [B][H][64][Lpad]
+  w.kv_lang_blk = ((size_t)B * D * (L + lpad64(L)) * a + 255) / 256 * 256;
+  w.kv_img_blk = ((size_t)B * D * (Li + lpad64(Li)) * a + 255) / 256 * 256;
   w.kv_lang = take(w.kv_lang_blk * n_lang_blk);
   w.kv_img = take(w.kv_img_blk * n_img_blk);
   const size_t M = (size_t)B * N;
@@ -189,12 +191,43 @@ int cache_cond(RCtx& c) {
     const int Lc = lang ? c.L : d.img_len;
     char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
     const void* src = lang ? c.ws + c.w.lang_c : c.ws + c.w.img_c;
-    VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
-    const bool fused = fuse_headnorm(p, b.ckn, D, nullptr, D, d.rms_mode);     // k_norm on the K half, in the GEMM epilogue
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cond kv"));
-    if (!fused) CK(vt_k_headnorm(kv, d.adt, 2 * D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
+    if (d.adt == VT_BF16) {
+      // bf16: K -> [B*Lc][D] (k_norm fused in the GEMM epilogue when it takes the large path); V -> tmpA -> Vt [B][H][64][Lpad]
+      const int Lp = lpad64(Lc);
+      VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
+      const bool fused = fuse_headnorm(pk, b.ckn, D, nullptr, D, d.rms_mode);
+      CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
+      if (!fused) CK(vt_k_headnorm(kv, d.adt, D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
+      VtGemmParams pv = lin(src, d.adt, D, (const char*)b.ckv_w + (size_t)D * D * c.a, d.cdt, D, b.ckv_b + D, c.ws + c.w.tmpA, d.adt, D, c.B * Lc, D, D,
+                            VT_ACT_NONE);
+      CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));
+      CK(vt_wrap(vt_k_transpose_v(c.ws + c.w.tmpA, D, kv + (size_t)c.B * Lc * D * c.a, c.B, Lc, Lp, d.heads, c.s), "rdt cond v transpose"));
+    } else {
+      VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
+      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cond kv"));
+      CK(vt_k_headnorm(kv, d.adt, 2 * D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
+    }
   }
   return VT_OK;
+}
+
+// cross-attention of N query rows per sample against block l's cached condition
+int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
+  const vt_rdt_desc& d = c.h->d;
+  const int D = d.hidden, a = c.a;
+  const bool lang = (l % 2) == 0;
+  const int Lc = lang ? c.L : d.img_len;
+  const char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
+  if (d.adt == VT_BF16) {
+    VtAttnKvtParams p;
+    memset(&p, 0, sizeof(p));
+    p.Q = c.ws + c.w.q; p.K = kv; p.VT = kv + (size_t)c.B * Lc * D * a; p.O = c.ws + c.w.att;
+    p.q_bs = (long)N * D; p.q_rs = D; p.k_bs = (long)Lc * D; p.k_rs = D; p.o_bs = (long)N * D; p.o_rs = D;
+    p.kmask = lang ? lang_mask : nullptr;
+    p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.Lpad = lpad64(Lc); p.scale = 0.125f;
+    return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
+  }
+  return attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att);
 }
 
 // blocks + final layer on the fp32 stream x [B*(horizon+3)][D]; writes out_tok [B*(horizon+3)][out_dim] (adt)
@@ -218,15 +251,12 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
       p.residual = x; p.ldr = D;
       CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt proj")); }
     // --- cross attention against the cached condition K/V
-    const bool lang = (l % 2) == 0;
-    const int Lc = lang ? c.L : d.img_len;
-    const char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
       const bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross q"));
       if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
-    CK(attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att));
+    CK(cross_attn(c, l, lang_mask, N));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
       CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross proj")); }
