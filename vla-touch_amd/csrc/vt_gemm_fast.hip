@@ -27,13 +27,15 @@ constexpr int BN = 128, BK = 64;
 constexpr int EP_LD = 68;                      // floats per row of the epilogue patch (64 + 4 pad, keeps 16-B alignment)
 constexpr int EP_BYTES = 32 * EP_LD * 4;       // per-wave patch: 32 rows x 64 columns fp32
 
-template <typename TC, int BM>
-__global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles) {
+// NS = LDS stages: 2 = the DMA of k-tile t+1 overlaps the MFMAs of tile t inside the block (2 blocks/CU);
+//                 1 = no overlap inside a block, latency is hidden by MINW (3-4) co-resident blocks per CU instead.
+template <typename TC, int BM, int NS, int MINW>
+__global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int TM = BM / 32;               // 16-row MFMA tiles per wave along M
   constexpr int QA = BM / 32;               // A-tile DMA instructions per wave
-  static_assert(2 * STAGE_BYTES >= 4 * EP_BYTES, "epilogue patches must fit in the operand stages");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE_BYTES];
+  constexpr int SMEM = NS * STAGE_BYTES > 4 * EP_BYTES ? NS * STAGE_BYTES : 4 * EP_BYTES;   // operand stages, reused by the epilogue patches
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -82,11 +84,18 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const VtGemmParams p,
     for (int j = 0; j < TM; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   const int nk = p.K / BK;
-  stage(0, 0);
-  __syncthreads();          // drains the DMA (vmcnt) and publishes stage 0
+  if constexpr (NS == 2) {
+    stage(0, 0);
+    __syncthreads();        // drains the DMA (vmcnt) and publishes stage 0
+  }
   for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    const int cur = NS == 2 ? (kt & 1) : 0;
+    if constexpr (NS == 2) {
+      if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
+    } else {
+      stage(0, kt);
+      __syncthreads();      // tile landed
+    }
     const char* As = smem + cur * STAGE_BYTES;
     const char* Bs = As + BM * 128;
 #pragma unroll
@@ -187,10 +196,11 @@ __global__ __launch_bounds__(256, 2) void gemm_glds_kernel(const VtGemmParams p,
 
 }  // namespace
 
-int g_vt_force_bm = 0;   // tuning hook (VLATOUCH_GEMM_BM=64|128)
+int g_vt_force_bm = 0;   // tuning hooks: VLATOUCH_GEMM_BM=64|128, VLATOUCH_GEMM_VARIANT=22|13|14
+int g_vt_variant = 0;    // 0 = choose per launch
 
 bool vt_gemm_fast_eligible(const VtGemmParams& p) {
-  static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); return true; }();
+  static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); e = getenv("VLATOUCH_GEMM_VARIANT"); if (e) g_vt_variant = atoi(e); return true; }();
   (void)init;
   if (p.a_dtype != VT_BF16 || p.w_dtype != VT_BF16 || p.taps != 0 || p.splitk != 1) return false;
   if (p.c_dtype != VT_BF16 && p.c_dtype != VT_F32) return false;
@@ -202,20 +212,33 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p) {
 
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p) { return vt_gemm_fast_eligible(p) && (p.N % 64) == 0; }
 
+template <typename TC, int BM>
+static void launch_variant(int variant, dim3 grid, hipStream_t s, const VtGemmParams& p, int tiles_n, int per_group, int total) {
+  switch (variant) {
+    case 13: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
+    case 14: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
+    default: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
+  }
+}
+
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   const int tiles_n = (p.N + BN - 1) / BN;
   const long tiles128 = (long)((p.M + 127) / 128) * tiles_n * p.groups;
-  // 512 block slots on the chip (256 CUs x 2): below ~4 waves of 128-row tiles, halve the tile to fill the machine
-  const int bm = (g_vt_force_bm == 64 || g_vt_force_bm == 128) ? g_vt_force_bm : (tiles128 < 2048 ? 64 : 128);
+  // Measured on MI355X (tools/gemm_bench.py): one LDS stage with 4 co-resident blocks per CU (1024 block slots) beats
+  // in-block double buffering at 2 blocks/CU on every shape of this path (cond-K/V 561 -> 854 TF/s, K=768 DINOv2 GEMMs
+  // 330 -> 490) except when the grid cannot fill the slots, where the two-stage kernel hides latency inside the block.
+  // 128-row tiles when they fill the slots, else 64-row tiles.
+  const int bm = (g_vt_force_bm == 64 || g_vt_force_bm == 128) ? g_vt_force_bm : (tiles128 < 1024 ? 64 : 128);
   const int tiles_m = (p.M + bm - 1) / bm;
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
+  const int variant = g_vt_variant ? g_vt_variant : (total < 768 ? 22 : 14);   // 22 = two stages, 2 blocks/CU; 13 / 14 = one stage, 3 / 4 blocks/CU
   VtProfScope prof(true, p, s);
   if (bm == 128) {
-    if (p.c_dtype == VT_BF16) hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, 128>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
-    else hipLaunchKernelGGL((gemm_glds_kernel<float, 128>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+    if (p.c_dtype == VT_BF16) launch_variant<bf16_t, 128>(variant, dim3(total), s, p, tiles_n, per_group, total);
+    else launch_variant<float, 128>(variant, dim3(total), s, p, tiles_n, per_group, total);
   } else {
-    if (p.c_dtype == VT_BF16) hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, 64>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
-    else hipLaunchKernelGGL((gemm_glds_kernel<float, 64>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total);
+    if (p.c_dtype == VT_BF16) launch_variant<bf16_t, 64>(variant, dim3(total), s, p, tiles_n, per_group, total);
+    else launch_variant<float, 64>(variant, dim3(total), s, p, tiles_n, per_group, total);
   }
   return vt_check_launch();
 }
