@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""HBM traffic of the dominant kernel class from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch).
+gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 128-B requests at 64 B -> doubled for wide coalesced reads.
+    python tools/pmc_summary.py gpurun_out/pmc/pmc_FETCH_SIZE_counter_collection.csv gpurun_out/pmc/pmc_WRITE_SIZE_counter_collection.csv"""
+import csv, sys, re
+from collections import defaultdict
+
+def load(path, counter):
+    agg = defaultdict(lambda: [0, 0.0])
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = re.sub(r"\(anonymous namespace\)::|void ", "", r["Kernel_Name"]).split("(")[0]
+            a = agg[name]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+
+fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+print("# per kernel: dispatches, HBM read GB (FETCH_SIZE KB x 2 gfx950 correction), HBM write GB (WRITE_SIZE KB), per-dispatch MB")
+rows = []
+for k in fetch:
+    n, f = fetch[k]
+    w = write.get(k, [0, 0.0])[1]
+    rows.append((2 * f * 1024 + w * 1024, k, n, 2 * f * 1024, w * 1024))
+for tot, k, n, rd, wr in sorted(rows, reverse=True)[:12]:
+    print(f"{k[:70]:70s} n={n:5d} read={rd/1e9:8.2f} GB write={wr/1e9:8.2f} GB  per-dispatch={(rd+wr)/n/1e6:9.2f} MB")
+g = [r for r in rows if "gemm_glds_kernel" in r[1]]
+tot = sum(r[0] for r in g); n = sum(r[2] for r in g)
+print(f"GEMM_GLDS_TOTAL dispatches={n} bytes={tot:.0f} per_launch_bytes={tot/max(n,1):.0f}")

@@ -18,6 +18,8 @@
 #include "vt_gemm.h"
 #include "vt_prof.h"
 
+int g_vt_gm = 0;         // m-tiles per super-row (VLATOUCH_GEMM_GM; 0 = choose per launch)
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -30,7 +32,7 @@ constexpr int EP_BYTES = 32 * EP_LD * 4;       // per-wave patch: 32 rows x 64 c
 // NS = LDS stages: 2 = the DMA of k-tile t+1 overlaps the MFMAs of tile t inside the block (2 blocks/CU);
 //                 1 = no overlap inside a block, latency is hidden by MINW (3-4) co-resident blocks per CU instead.
 template <typename TC, int BM, int NS, int MINW>
-__global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles) {
+__global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int TM = BM / 32;               // 16-row MFMA tiles per wave along M
   constexpr int QA = BM / 32;               // A-tile DMA instructions per wave
@@ -45,7 +47,14 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
   if ((total_tiles & 7) == 0) bid = (bid & 7) * (total_tiles >> 3) + (bid >> 3);     // XCD b%8 gets a contiguous band
   const int grp = bid / tiles_per_group;
   const int t_in = bid - grp * tiles_per_group;
-  const int tm = t_in / tiles_n, tn = t_in - tm * tiles_n;
+  // tile order inside a group: super-rows of GM m-tiles; within a super-row n advances slowly and m fastest, so GM
+  // consecutive blocks share one W tile and the GM A panels stay L2-resident across all n (W is re-read tiles_m/GM times
+  // instead of tiles_m times; PMC FETCH showed 2.5x the algorithmic bytes with the plain n-fastest order).
+  const int tiles_m = tiles_per_group / tiles_n;
+  const int sr = t_in / (GM * tiles_n);
+  const int gm = min(GM, tiles_m - sr * GM);
+  const int r_in = t_in - sr * GM * tiles_n;
+  const int tn = r_in / gm, tm = sr * GM + (r_in - tn * gm);
   const int m0 = tm * BM, n0 = tn * BN;
 
   const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)grp * p.a_gs;
@@ -200,7 +209,7 @@ int g_vt_force_bm = 0;   // tuning hooks: VLATOUCH_GEMM_BM=64|128, VLATOUCH_GEMM
 int g_vt_variant = 0;    // 0 = choose per launch
 
 bool vt_gemm_fast_eligible(const VtGemmParams& p) {
-  static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); e = getenv("VLATOUCH_GEMM_VARIANT"); if (e) g_vt_variant = atoi(e); return true; }();
+  static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); e = getenv("VLATOUCH_GEMM_VARIANT"); if (e) g_vt_variant = atoi(e); e = getenv("VLATOUCH_GEMM_GM"); if (e) g_vt_gm = atoi(e); return true; }();
   (void)init;
   if (p.a_dtype != VT_BF16 || p.w_dtype != VT_BF16 || p.taps != 0 || p.splitk != 1) return false;
   if (p.c_dtype != VT_BF16 && p.c_dtype != VT_F32) return false;
@@ -214,10 +223,13 @@ bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p) { return vt_gemm_fast_elig
 
 template <typename TC, int BM>
 static void launch_variant(int variant, dim3 grid, hipStream_t s, const VtGemmParams& p, int tiles_n, int per_group, int total) {
+  // super-row height (measured): tall-skinny outputs (few n-tiles, many m-tiles: the condition K/V projections) like 16,
+  // everything else 4
+  const int gm = g_vt_gm > 0 ? g_vt_gm : ((tiles_n <= 16 && per_group / tiles_n >= 128) ? 16 : 4);
   switch (variant) {
-    case 13: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
-    case 14: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
-    default: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total); break;
+    case 13: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
+    case 14: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
+    default: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
   }
 }
 
