@@ -144,10 +144,10 @@ def test_groupnorm_mish_film_residual(dev, T, Cc):
     assert rel_err(ops.groupnorm_cl(slabs, bias, gamma, beta, B=B, T=T, residual=res), ref2) < 2e-5
 
 
-@pytest.mark.parametrize("D", [256, 384, 768, 2048])
-def test_rownorm_modes(dev, D):
+@pytest.mark.parametrize("D,rows", [(256, 37), (384, 37), (768, 37), (2048, 37), (2048, 300), (1152, 261)])
+def test_rownorm_modes(dev, D, rows):
     from vlatouch import ops, _lib as L
-    x, w, b = rnd((37, D), 1, dev), rnd((D,), 2, dev) + 1, rnd((D,), 3, dev)
+    x, w, b = rnd((rows, D), 1, dev), rnd((D,), 2, dev) + 1, rnd((D,), 3, dev)
     assert rel_err(ops.rownorm(x, w, b, 1e-6), F.layer_norm(x, (D,), w, b, 1e-6)) < 2e-5
     ref = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + 1e-6) * w
     assert rel_err(ops.rownorm(x, w, None, 1e-6, L.NORM_RMS_MEANSQ), ref) < 2e-5

@@ -72,6 +72,67 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const TI* __restrict__ x, 
   }
 }
 
+// wide rows (D >= 1024, fp32 in): one 256-thread block per row, 16-B loads, two-level (wave, LDS) reductions — 4x the
+// blocks of the wave-per-row kernel for the [B*67, 2048] RMSNorms of the RDT step loop
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restrict__ x, long ldx, TO* __restrict__ y, long ldy, const float* __restrict__ w,
+                                                            const float* __restrict__ b, int D, float eps, int mode) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float* xr = x + (long)blockIdx.x * ldx;
+  const int nv = D >> 2;
+  float4 v[NV];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = tid + 256 * i;
+    v[i] = c4 < nv ? *reinterpret_cast<const float4*>(xr + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  auto block_sum = [&](float t) {
+    t = wave_sum(t);
+    __syncthreads();
+    if (lane == 0) red[wv] = t;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float mean = 0.f, var;
+  if (mode == VT_NORM_RMS_MEANSQ) {
+    var = block_sum(q) / (float)D;
+  } else {
+    mean = block_sum(s) / (float)D;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (tid + 256 * i < nv) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        d2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    d2 = block_sum(d2);
+    var = (mode == VT_NORM_RMS_VAR) ? d2 / (float)(D - 1) : d2 / (float)D;
+    if (mode == VT_NORM_RMS_VAR) mean = 0.f;
+  }
+  const float rstd = rsqrtf(var + eps);
+  TO* yr = y + (long)blockIdx.x * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = tid + 256 * i;
+    if (c4 < nv) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c4 * 4);
+      float o[4] = {(v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y, (v[i].z - mean) * rstd * ww.z, (v[i].w - mean) * rstd * ww.w};
+      if (b) { const float4 bb = *reinterpret_cast<const float4*>(b + c4 * 4); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+      if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(yr + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      else {
+        uint2 t;
+        t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
+        t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
+        *reinterpret_cast<uint2*>(yr + c4 * 4) = t;
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ per-head RMSNorm on 64-wide rows (q / k norm)
 template <typename T>
 __global__ __launch_bounds__(256) void headnorm_kernel(T* __restrict__ x, long tok_stride, int heads, long rows,
@@ -325,6 +386,11 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
                  float eps, int mode, hipStream_t s) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
+  if (xdt == VT_F32 && D >= 1024 && rows >= 256 && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row
+    if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
+    else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode);
+    return vt_check_launch();
+  }
   dim3 grid((rows + 3) / 4);
   DISPATCH_T(xdt, TI, DISPATCH_T(ydt, TO, {
     if (D <= 1024) hipLaunchKernelGGL((rownorm_kernel<TI, TO, 4>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode);

@@ -107,11 +107,14 @@ class DiffusionController:
                        eng.in_pad, eng.adt, torch.device(self.device))
         return eng(x)
 
-    def predict(self, state, vla_actions, images_cam1=None, images_cam2=None, forces=None, noise=None):
-        """Refined actions [B, horizon, state_dim] in the expert action scale (bridge_controller.py:149-182)."""
+    def predict(self, state, vla_actions, images_cam1=None, images_cam2=None, forces=None, noise=None, obs_cond=None):
+        """Refined actions [B, horizon, state_dim] in the expert action scale (bridge_controller.py:149-182).
+        `obs_cond=` (extension) passes an observation encoding computed earlier by `encode_observation`, e.g. on a second
+        HIP stream while the VLA chunk is still being generated."""
         self.eval()
         with torch.no_grad():
-            obs_cond = self.encode_observation(state, images_cam1, images_cam2, forces)
+            if obs_cond is None:
+                obs_cond = self.encode_observation(state, images_cam1, images_cam2, forces)
             vla_actions_n = normalize_actions(torch.as_tensor(vla_actions).to(self.device), self.stats, 'vla')
             refined_actions_n = self.diffusion_model.sample(x_prior=vla_actions_n, cond=obs_cond,
                                                             diffuse_step=self.diffusion_steps, noise=noise)
