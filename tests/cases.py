@@ -151,6 +151,35 @@ def predict_inputs(B: int, Tlen: int, res: int, seed: int = 4):
     return dict(state=T(state), forces=T(forces), vla=T(vla), cam1=T(cam1), cam2=T(cam2), z=T(z))
 
 
+def synth_episode(seed: int, N: int, res: int = 28) -> Dict[str, np.ndarray]:
+    """A synthetic episode in the reference's on-disk key layout (4_convert_to_hdf5.py; NPZ container, '/' for groups):
+    the first 4 frames are static (exercises the first-motion trim), then a smooth pose walk."""
+    g = synth.inputs_rng(seed)
+    pos = np.zeros((N, 3))
+    pos[4:] = np.cumsum(g.normal(0, 0.02, (N - 4, 3)), axis=0)
+    pos += g.normal(0, 0.3, (1, 3))
+    ang = np.zeros((N, 3))
+    ang[4:] = np.cumsum(g.normal(0, 0.03, (N - 4, 3)), axis=0)
+    half = ang / 2
+    quat = np.stack([np.sin(half[:, 0]), np.sin(half[:, 1]) * 0.5, np.sin(half[:, 2]) * 0.25,
+                     np.cos(half[:, 0])], axis=1)
+    quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+    grip = np.clip(128 + np.cumsum(g.normal(0, 6, N)), 0, 255)
+    expert = None
+    vla = g.normal(0, 0.2, (N, 64, 10))
+    vla[:, :, :3] += pos[:, None, :]
+    vla[:, :, -1] = np.clip(grip[:, None] + g.normal(0, 10, (N, 64)), 0, 255)
+    return {
+        "ee_poses": np.concatenate([pos, quat], axis=1).astype(np.float64),
+        "gripper_pos": grip.astype(np.float64),
+        "vla_action": vla.astype(np.float64),
+        "gelsight_force/forces": g.normal(0, 1, (N, 3)).astype(np.float64),
+        "gelsight_force/displacement": g.normal(0, 1, (N, 63, 2)).astype(np.float32),
+        "camera1_resized": (255 * (0.2 + 0.8 * g.random((N, res, res, 3)))).astype(np.uint8),
+        "camera2_resized": (255 * (0.6 * g.random((N, res, res, 3)))).astype(np.uint8),
+    }
+
+
 def lstm_inputs(B: int, Tlen: int, seed: int = 5):
     g = synth.inputs_rng(seed)
     return dict(obs_cond=T(g.standard_normal((B, 256), dtype=np.float32)),
