@@ -40,10 +40,9 @@ def test_predict_end_to_end_golden(controllers, prec):
     assert pred.shape == (2, 16, 10) and pred.dtype == torch.float32
     e_obs, e_pred = err(obs, g["obs_cond"]), err(pred, g["pred"])
     print(f"[{prec}] obs_cond err {e_obs:.3e}  a_hat err {e_pred:.3e}")
-    assert e_obs < (2e-4 if prec == "fp32" else 3e-2), e_obs
-    # KNOWN GAP: bf16 end-to-end is 1.24e-2 on this case, above the 1e-2 target — bf16 DINOv2 feature error
-    # (6.9e-3 on obs_cond) is amplified by FiLM + the SDE score gain.  The bound below is the measured value, not the target.
-    assert e_pred < (TOL[prec] if prec == "fp32" else 1.5e-2), e_pred
+    assert e_obs < (2e-4 if prec == "fp32" else 5e-3), e_obs
+    # north_star tolerance on a_hat: 1e-4 fp32, 1e-2 low precision ("bf16" mode = fp16 DINOv2 + bf16 MLP + split-bf16 U-Nets)
+    assert e_pred < TOL[prec], e_pred
 
 
 def test_predict_draws_its_own_noise(controllers):

@@ -39,23 +39,24 @@ ACTS = {0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approxima
 
 
 @pytest.mark.parametrize("M,N,K", [(32, 256, 784), (70, 100, 40), (512, 512, 1280), (1000, 768, 592), (4112, 2304, 768), (33, 10, 256)])
-@pytest.mark.parametrize("mode", ["f32", "bf16", "a32w16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "a32w16", "f16"])
 def test_gemm_plain(dev, M, N, K, mode):
     from vlatouch import ops
-    adt = torch.bfloat16 if mode == "bf16" else torch.float32
-    wdt = torch.float32 if mode == "f32" else torch.bfloat16
+    lo = torch.float16 if mode == "f16" else torch.bfloat16
+    adt = lo if mode in ("bf16", "f16") else torch.float32
+    wdt = torch.float32 if mode == "f32" else lo
     a = rnd((M, K), 1, dev, adt)
     w = rnd((N, K), 2, dev, wdt, K ** -0.5)
     bias = rnd((N,), 3, dev)
     cs = rnd((N,), 4, dev) + 1.0
     act = (M + N) % 5
-    for odt in ((torch.float32,) if mode == "f32" else (torch.float32, torch.bfloat16)):
+    for odt in ((torch.float32,) if mode == "f32" else (torch.float32, lo)):
         res = rnd((M, N), 5, dev, odt)
         ref = res.float() + cs * ACTS[act](a.float() @ w.float().t() + bias)
         if mode == "a32w16":
             ref = res.float() + cs * ACTS[act](a.to(torch.bfloat16).float() @ w.float().t() + bias)
         out = ops.gemm(a, w, bias, act=act, colscale=cs, residual=res, out_dtype=odt)
-        tol = 2e-5 if (mode == "f32") else (2e-3 if odt == torch.float32 else 1e-2)
+        tol = 2e-5 if (mode == "f32") else (2e-3 if odt == torch.float32 else (2e-3 if mode == "f16" else 1e-2))
         assert rel_err(out.float(), ref) < tol, (mode, odt, rel_err(out.float(), ref))
 
 
@@ -107,11 +108,11 @@ def test_conv_transpose_parity_split(dev):
     assert rel_err(out, ref) < 2e-5
 
 
-@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("Nq,Nk,masked", [(257, 257, False), (67, 67, False), (67, 40, True), (67, 1000, False), (5, 730, False)])
 def test_attention(dev, mode, Nq, Nk, masked):
     from vlatouch import ops
-    dt = torch.float32 if mode == "f32" else torch.bfloat16
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode]
     B, H = 2, 3
     qkv = rnd((B, max(Nq, Nk), 3, H, 64), 1, dev, dt)
     q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
@@ -125,7 +126,7 @@ def test_attention(dev, mode, Nq, Nk, masked):
     if mask is not None:
         s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, Nq, H * 64)
-    assert rel_err(out.float(), ref) < (3e-5 if mode == "f32" else 1.5e-2)
+    assert rel_err(out.float(), ref) < {"f32": 3e-5, "bf16": 1.5e-2, "f16": 2e-3}[mode]
 
 
 @pytest.mark.parametrize("T,Cc", [(16, 256), (8, 512), (4, 512), (48, 256), (64, 256)])

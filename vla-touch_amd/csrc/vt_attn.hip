@@ -18,6 +18,11 @@ template <> struct QLoad<bf16_t> {
     f.v = ok ? *reinterpret_cast<const short8_t*>(p) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
   }
 };
+template <> struct QLoad<half_t> {
+  __device__ static __forceinline__ void ld(Frag<half_t>& f, const half_t* p, bool ok) {
+    f.v = ok ? *reinterpret_cast<const short8_t*>(p) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  }
+};
 template <> struct QLoad<float> {
   __device__ static __forceinline__ void ld(Frag<float>& f, const float* p, bool ok) {
 #pragma unroll
@@ -32,6 +37,12 @@ template <> struct PackP<bf16_t> {
     for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(p[j]);
   }
 };
+template <> struct PackP<half_t> {
+  __device__ static __forceinline__ void pack(Frag<half_t>& f, const float p[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = (short)f2h(p[j]).b;
+  }
+};
 template <> struct PackP<float> {
   __device__ static __forceinline__ void pack(Frag<float>& f, const float p[8]) {
 #pragma unroll
@@ -42,6 +53,13 @@ template <> struct PackP<float> {
 template <typename T> struct VtRead;   // 4 consecutive keys of one d row
 template <> struct VtRead<bf16_t> {
   __device__ static __forceinline__ void rd(Frag<bf16_t>& f, int half, const char* p) {
+    const uint2 t = *reinterpret_cast<const uint2*>(p);
+    f.v[half * 4 + 0] = (short)(t.x & 0xffff); f.v[half * 4 + 1] = (short)(t.x >> 16);
+    f.v[half * 4 + 2] = (short)(t.y & 0xffff); f.v[half * 4 + 3] = (short)(t.y >> 16);
+  }
+};
+template <> struct VtRead<half_t> {
+  __device__ static __forceinline__ void rd(Frag<half_t>& f, int half, const char* p) {
     const uint2 t = *reinterpret_cast<const uint2*>(p);
     f.v[half * 4 + 0] = (short)(t.x & 0xffff); f.v[half * 4 + 1] = (short)(t.x >> 16);
     f.v[half * 4 + 2] = (short)(t.y & 0xffff); f.v[half * 4 + 3] = (short)(t.y >> 16);
@@ -187,7 +205,8 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
-  const int epc = p.dtype == VT_BF16 ? 8 : 4;
+  if (p.dtype != VT_F32 && p.dtype != VT_BF16 && p.dtype != VT_F16) return VT_ERR_UNSUPPORTED;
+  const int epc = p.dtype == VT_F32 ? 4 : 8;
   if (p.q_rs % epc || p.k_rs % epc || p.v_rs % epc || p.q_hs % epc || p.k_hs % epc || p.v_hs % epc) return VT_ERR_ARG;
   int nw = 4, best = 1 << 30;
   for (int w = 4; w <= 8; ++w) {                      // fewest padded query rows; ties -> fewer waves
@@ -197,6 +216,7 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   const int rows = nw * 16;
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
   if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(64 * nw), 0, s, p);
+  else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t>), grid, dim3(64 * nw), 0, s, p);
   else hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(64 * nw), 0, s, p);
   return vt_check_launch();
 }

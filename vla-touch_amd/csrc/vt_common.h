@@ -13,13 +13,17 @@ typedef uint16_t bf16_t;  // raw bits
 typedef __attribute__((ext_vector_type(8))) short short8_t;
 typedef __attribute__((ext_vector_type(4))) float float4_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+struct half_t { uint16_t b; };   // raw IEEE binary16 bits, a distinct type so templates can tell it from bf16_t
 
 #define VT_OK 0
 #define VT_ERR_ARG (-22)
 #define VT_ERR_LAUNCH (-5)
 #define VT_ERR_UNSUPPORTED (-95)
 
-enum { VT_F32 = 0, VT_BF16 = 1, VT_F32X3 = 2 };   // F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only)
+// F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only).  F16: IEEE half storage + v_mfma_f32_16x16x32_f16
+// (same rate as bf16, 3 more mantissa bits; used where activations are range-bounded, i.e. the DINOv2 encoders).
+enum { VT_F32 = 0, VT_BF16 = 1, VT_F32X3 = 2, VT_F16 = 3 };
 enum { VT_ACT_NONE = 0, VT_ACT_GELU_ERF = 1, VT_ACT_GELU_TANH = 2, VT_ACT_SILU = 3, VT_ACT_MISH = 4 };
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
@@ -29,6 +33,8 @@ __device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
+__device__ __forceinline__ float h2f(half_t h) { return (float)__builtin_bit_cast(_Float16, h.b); }
+__device__ __forceinline__ half_t f2h(float f) { half_t r; r.b = __builtin_bit_cast(uint16_t, (_Float16)f); return r; }   // v_cvt_f16_f32: RNE, saturates to inf
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -41,14 +47,23 @@ template <> struct Elem<bf16_t> {
   __device__ static __forceinline__ float to_f(bf16_t v) { return bf2f(v); }
   __device__ static __forceinline__ bf16_t from_f(float v) { return f2bf(v); }
 };
+template <> struct Elem<half_t> {
+  static constexpr int EPC = 8;
+  __device__ static __forceinline__ float to_f(half_t v) { return h2f(v); }
+  __device__ static __forceinline__ half_t from_f(float v) { return f2h(v); }
+};
 
 // 8-element fragment of compute type T
 template <typename T> struct Frag;
 template <> struct Frag<bf16_t> { short8_t v; };
+template <> struct Frag<half_t> { short8_t v; };
 template <> struct Frag<float> { float v[8]; };
 
 __device__ __forceinline__ void mma16(float4_t& acc, const Frag<bf16_t>& a, const Frag<bf16_t>& b) {
   acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a.v), __builtin_bit_cast(bf16x8_t, b.v), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma16(float4_t& acc, const Frag<half_t>& a, const Frag<half_t>& b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a.v), __builtin_bit_cast(f16x8_t, b.v), acc, 0, 0, 0);
 }
 __device__ __forceinline__ void mma16(float4_t& acc, const Frag<float>& a, const Frag<float>& b) {
 #pragma unroll
@@ -60,6 +75,9 @@ __device__ __forceinline__ void mma16(float4_t& acc, const Frag<float>& a, const
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((row >> 1) & 7); }
 
 __device__ __forceinline__ void lds_frag(Frag<bf16_t>& f, const char* tile, int row, int k8) {
+  f.v = *reinterpret_cast<const short8_t*>(tile + row * 128 + swz(row, k8) * 16);
+}
+__device__ __forceinline__ void lds_frag(Frag<half_t>& f, const char* tile, int row, int k8) {
   f.v = *reinterpret_cast<const short8_t*>(tile + row * 128 + swz(row, k8) * 16);
 }
 __device__ __forceinline__ void lds_frag(Frag<float>& f, const char* tile, int row, int k8) {
@@ -100,8 +118,10 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
 template <> __device__ __forceinline__ float ldf<float>(const float* p, size_t i) { return p[i]; }
 template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, size_t i) { return bf2f(p[i]); }
+template <> __device__ __forceinline__ float ldf<half_t>(const half_t* p, size_t i) { return h2f(p[i]); }
 template <typename T> __device__ __forceinline__ void stf(T* p, size_t i, float v);
 template <> __device__ __forceinline__ void stf<float>(float* p, size_t i, float v) { p[i] = v; }
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
+template <> __device__ __forceinline__ void stf<half_t>(half_t* p, size_t i, float v) { p[i] = f2h(v); }
 
 static inline int vt_check_launch() { return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH; }

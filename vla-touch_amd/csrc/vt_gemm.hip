@@ -76,6 +76,18 @@ template <> struct Store4<bf16_t> {
   }
 };
 
+template <> struct Store4<half_t> {
+  __device__ static __forceinline__ void st(half_t* p, const float v[4]) {
+    half_t t[4] = {f2h(v[0]), f2h(v[1]), f2h(v[2]), f2h(v[3])};
+    *reinterpret_cast<uint2*>(p) = *reinterpret_cast<const uint2*>(t);
+  }
+  __device__ static __forceinline__ void ld(const half_t* p, float v[4]) {
+    half_t t[4];
+    *reinterpret_cast<uint2*>(t) = *reinterpret_cast<const uint2*>(p);
+    v[0] = h2f(t[0]); v[1] = h2f(t[1]); v[2] = h2f(t[2]); v[3] = h2f(t[3]);
+  }
+};
+
 template <typename TA, typename TW, typename TC, int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(const VtGemmParams p) {
   static_assert(WM * WN == 4, "4 waves");
@@ -314,7 +326,14 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (vt_gemm_fast_eligible(p)) return vt_gemm_fast_launch(p, s);     // large bf16 GEMMs: LDS-DMA pipeline (vt_gemm_fast.hip)
   if (p.hn_w0 || p.hn_w1) return VT_ERR_UNSUPPORTED;                   // fused head-norm exists only on the fast path
   if (p.a_dtype == VT_BF16 && p.w_dtype == VT_BF16) {
-    return p.c_dtype == VT_BF16 ? launch_cfg<bf16_t, bf16_t, bf16_t>(p, s) : launch_cfg<bf16_t, bf16_t, float>(p, s);
+    if (p.c_dtype == VT_BF16) return launch_cfg<bf16_t, bf16_t, bf16_t>(p, s);
+    if (p.c_dtype == VT_F32) return launch_cfg<bf16_t, bf16_t, float>(p, s);
+    return VT_ERR_UNSUPPORTED;
+  }
+  if (p.a_dtype == VT_F16 && p.w_dtype == VT_F16) {
+    if (p.c_dtype == VT_F16) return launch_cfg<half_t, half_t, half_t>(p, s);
+    if (p.c_dtype == VT_F32) return launch_cfg<half_t, half_t, float>(p, s);
+    return VT_ERR_UNSUPPORTED;
   }
   if (p.a_dtype == VT_F32 && p.w_dtype == VT_BF16) {
     return p.c_dtype == VT_BF16 ? launch_cfg<float, bf16_t, bf16_t>(p, s) : launch_cfg<float, bf16_t, float>(p, s);

@@ -1,13 +1,15 @@
-// vt_gemm_fast.hip — the large-GEMM path: bf16 x bf16 -> fp32 accumulate on v_mfma_f32_16x16x32_bf16, for every big
-// Linear of RDT and DINOv2 (C = epilogue(A[M,K] W[N,K]^T), K % 64 == 0).
+// vt_gemm_fast.hip — the large-GEMM path: 16-bit x 16-bit -> fp32 accumulate on v_mfma_f32_16x16x32_{bf16,f16}, for every
+// big Linear of RDT (bf16) and DINOv2 (IEEE fp16) (C = epilogue(A[M,K] W[N,K]^T), K % 64 == 0).
 //
 // Structure: BM x 128 x 64 block tile (BM = 128 or 64), 256 threads = 4 waves (2x2), each wave (BM/2) x 64 output =
 // (BM/32) x 4 MFMA tiles.  Operand tiles go HBM/L2 -> LDS by DMA (`global_load_lds_dwordx4`, 16 B per lane, no VGPR
 // round trip): a wave instruction fills 1 KiB = 8 rows x 128 B of the tile; the LDS image is lane-linear, so the XOR
 // chunk swizzle that makes the 16-row fragment reads (ds_read_b128) bank-conflict-free is applied to the SOURCE
-// address of each lane and again on the read (same involution both sides).  Two LDS stages (2 blocks/CU): the DMA of
-// k-tile t+1 is issued before the MFMAs of tile t; one barrier per k-tile.  Blocks are dealt to XCDs in contiguous
-// bands of tiles so neighbouring tiles share operand panels in that XCD's private L2.
+// address of each lane and again on the read (same involution both sides).  Two pipelining variants (picked per launch
+// from the grid size, see vt_gemm_fast_launch): ONE LDS stage with 4 co-resident blocks per CU (latency hidden across
+// blocks; the default whenever the grid fills the 1024 block slots) or TWO stages at 2 blocks/CU (DMA of k-tile t+1 issued
+// before the MFMAs of tile t).  Blocks are dealt to XCDs in contiguous bands of tiles, and inside a band in super-rows of
+// GM m-tiles, so neighbouring tiles share operand panels in that XCD's private L2.
 // Operands are swapped (D = W_tile A_tile^T) so a lane ends with 4 consecutive n of one row m.
 // Epilogue: + bias, optional per-head RMSNorm (q_norm / k_norm of timm Attention: a wave's 64 columns are exactly
 // one head, the row's 64 values live in the 4 lanes sharing lane&15 -> two shuffles), activation, column scale
@@ -31,7 +33,7 @@ constexpr int EP_BYTES = 32 * EP_LD * 4;       // per-wave patch: 32 rows x 64 c
 
 // NS = LDS stages: 2 = the DMA of k-tile t+1 overlaps the MFMAs of tile t inside the block (2 blocks/CU);
 //                 1 = no overlap inside a block, latency is hidden by MINW (3-4) co-resident blocks per CU instead.
-template <typename TC, int BM, int NS, int MINW>
+template <typename T16, typename TC, int BM, int NS, int MINW>
 __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int TM = BM / 32;               // 16-row MFMA tiles per wave along M
@@ -57,13 +59,13 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
   const int tn = r_in / gm, tm = sr * GM + (r_in - tn * gm);
   const int m0 = tm * BM, n0 = tn * BN;
 
-  const bf16_t* A = reinterpret_cast<const bf16_t*>(p.A) + (long)grp * p.a_gs;
-  const bf16_t* W = reinterpret_cast<const bf16_t*>(p.W) + (long)grp * p.w_gs;
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (long)grp * p.a_gs;
+  const uint16_t* W = reinterpret_cast<const uint16_t*>(p.W) + (long)grp * p.w_gs;
 
   // DMA sources: instruction q of this wave fills 8 LDS rows; lane -> (row, chunk position); it fetches the chunk whose
   // swizzled position is its own.  Rows beyond M / N are clamped (computed, never stored).
-  const bf16_t* a_src[QA];
-  const bf16_t* b_src[4];
+  const uint16_t* a_src[QA];
+  const uint16_t* b_src[4];
 #pragma unroll
   for (int q = 0; q < QA; ++q) {
     const int r = (wave * QA + q) * 8 + (lane >> 3);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
     const char* Bs = As + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      Frag<bf16_t> af[TM], wf[4];
+      Frag<T16> af[TM], wf[4];
 #pragma unroll
       for (int j = 0; j < TM; ++j) lds_frag(af[j], As, wm * (BM / 2) + j * 16 + l15, ks * 4 + g);
 #pragma unroll
@@ -189,14 +191,15 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
           *reinterpret_cast<float4*>(Cg + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
           if (Rg) {
-            const uint2 t = *reinterpret_cast<const uint2*>(Rg + (long)m * p.ldr + n);
-            o[0] += __uint_as_float(t.x << 16); o[1] += __uint_as_float(t.x & 0xffff0000u);
-            o[2] += __uint_as_float(t.y << 16); o[3] += __uint_as_float(t.y & 0xffff0000u);
+            TC rv[4];
+            *reinterpret_cast<uint2*>(rv) = *reinterpret_cast<const uint2*>(Rg + (long)m * p.ldr + n);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += Elem<TC>::to_f(rv[r]);
           }
-          uint2 t;
-          t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-          t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-          *reinterpret_cast<uint2*>(Cg + (long)m * p.ldc + n) = t;
+          TC ov[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov[r] = Elem<TC>::from_f(o[r]);
+          *reinterpret_cast<uint2*>(Cg + (long)m * p.ldc + n) = *reinterpret_cast<const uint2*>(ov);
         }
       }
     }
@@ -211,8 +214,8 @@ int g_vt_variant = 0;    // 0 = choose per launch
 bool vt_gemm_fast_eligible(const VtGemmParams& p) {
   static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); e = getenv("VLATOUCH_GEMM_VARIANT"); if (e) g_vt_variant = atoi(e); e = getenv("VLATOUCH_GEMM_GM"); if (e) g_vt_gm = atoi(e); return true; }();
   (void)init;
-  if (p.a_dtype != VT_BF16 || p.w_dtype != VT_BF16 || p.taps != 0 || p.splitk != 1) return false;
-  if (p.c_dtype != VT_BF16 && p.c_dtype != VT_F32) return false;
+  if ((p.a_dtype != VT_BF16 && p.a_dtype != VT_F16) || p.w_dtype != p.a_dtype || p.taps != 0 || p.splitk != 1) return false;
+  if (p.c_dtype != p.a_dtype && p.c_dtype != VT_F32) return false;
   if (p.K % BK || p.lda % 8 || p.ldw % 8 || p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)) return false;
   if (p.M < 128) return false;
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.groups;
@@ -221,15 +224,15 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p) {
 
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p) { return vt_gemm_fast_eligible(p) && (p.N % 64) == 0; }
 
-template <typename TC, int BM>
+template <typename T16, typename TC, int BM>
 static void launch_variant(int variant, dim3 grid, hipStream_t s, const VtGemmParams& p, int tiles_n, int per_group, int total) {
   // super-row height (measured): tall-skinny outputs (few n-tiles, many m-tiles: the condition K/V projections) like 16,
   // everything else 4
   const int gm = g_vt_gm > 0 ? g_vt_gm : ((tiles_n <= 16 && per_group / tiles_n >= 128) ? 16 : 4);
   switch (variant) {
-    case 13: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
-    case 14: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
-    default: hipLaunchKernelGGL((gemm_glds_kernel<TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
+    case 13: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
+    case 14: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
+    default: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
   }
 }
 
@@ -245,12 +248,15 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
   const int variant = g_vt_variant ? g_vt_variant : (total < 768 ? 22 : 14);   // 22 = two stages, 2 blocks/CU; 13 / 14 = one stage, 3 / 4 blocks/CU
   VtProfScope prof(true, p, s);
-  if (bm == 128) {
-    if (p.c_dtype == VT_BF16) launch_variant<bf16_t, 128>(variant, dim3(total), s, p, tiles_n, per_group, total);
-    else launch_variant<float, 128>(variant, dim3(total), s, p, tiles_n, per_group, total);
+#define VT_FAST_GO(T16, TC, BMv) launch_variant<T16, TC, BMv>(variant, dim3(total), s, p, tiles_n, per_group, total)
+  const bool c16 = p.c_dtype != VT_F32;
+  if (p.a_dtype == VT_BF16) {
+    if (bm == 128) { if (c16) VT_FAST_GO(bf16_t, bf16_t, 128); else VT_FAST_GO(bf16_t, float, 128); }
+    else           { if (c16) VT_FAST_GO(bf16_t, bf16_t, 64);  else VT_FAST_GO(bf16_t, float, 64); }
   } else {
-    if (p.c_dtype == VT_BF16) launch_variant<bf16_t, 64>(variant, dim3(total), s, p, tiles_n, per_group, total);
-    else launch_variant<float, 64>(variant, dim3(total), s, p, tiles_n, per_group, total);
+    if (bm == 128) { if (c16) VT_FAST_GO(half_t, half_t, 128); else VT_FAST_GO(half_t, float, 128); }
+    else           { if (c16) VT_FAST_GO(half_t, half_t, 64);  else VT_FAST_GO(half_t, float, 64); }
   }
+#undef VT_FAST_GO
   return vt_check_launch();
 }

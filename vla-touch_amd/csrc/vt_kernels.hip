@@ -124,10 +124,8 @@ __global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restr
       if (b) { const float4 bb = *reinterpret_cast<const float4*>(b + c4 * 4); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
       if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(yr + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
       else {
-        uint2 t;
-        t.x = (uint32_t)f2bf(o[0]) | ((uint32_t)f2bf(o[1]) << 16);
-        t.y = (uint32_t)f2bf(o[2]) | ((uint32_t)f2bf(o[3]) << 16);
-        *reinterpret_cast<uint2*>(yr + c4 * 4) = t;
+        TO t[4] = {Elem<TO>::from_f(o[0]), Elem<TO>::from_f(o[1]), Elem<TO>::from_f(o[2]), Elem<TO>::from_f(o[3])};
+        *reinterpret_cast<uint2*>(yr + c4 * 4) = *reinterpret_cast<const uint2*>(t);
       }
     }
   }
@@ -381,13 +379,14 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 
 // =============================================================================== host launchers
 #define DISPATCH_T(dt, T, ...) \
-  if ((dt) == VT_F32) { using T = float; __VA_ARGS__; } else { using T = bf16_t; __VA_ARGS__; }
+  if ((dt) == VT_F32) { using T = float; __VA_ARGS__; } else if ((dt) == VT_F16) { using T = half_t; __VA_ARGS__; } else { using T = bf16_t; __VA_ARGS__; }
 
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
                  float eps, int mode, hipStream_t s) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
   if (xdt == VT_F32 && D >= 1024 && rows >= 256 && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row
     if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
+    else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode);
     else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode);
     return vt_check_launch();
   }

@@ -20,7 +20,7 @@
 #include "../../include/vlatouch.h"
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
-static int es(int dt) { return dt == VT_BF16 ? 2 : 4; }
+static int es(int dt) { return (dt == VT_BF16 || dt == VT_F16) ? 2 : 4; }
 
 static VtGemmParams lin(const void* A, int adt, long lda, const void* W, int cdt, long ldw, const float* b, void* C, int odt, long ldc,
                         int M, int N, int K, int act) {

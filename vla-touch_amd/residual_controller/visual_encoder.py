@@ -89,7 +89,13 @@ class DINOv2Encoder:
                     f"no DINOv2 weights for {model_name!r}: pass state_dict=, point model_name at a local HF directory, "
                     "or set VLATOUCH_SYNTH_WEIGHTS=1 for deterministic synthetic weights (no network access here)")
         self._state_dict = sd
-        self.engine = DinoEngine(sd, heads=cfg["heads"], precision=self.precision, device=device)
+        # the low-precision mode of the ENCODER is IEEE fp16 (same MFMA rate as bf16, 3 more mantissa bits; the residual stream
+        # stays fp32 so activations are range-safe): bf16 features alone cost 7e-3 on obs_cond, most of the 1e-2 budget on a_t.
+        # VLATOUCH_DINO_PRECISION=bf16 restores bf16 storage.
+        eng_prec = self.precision
+        if eng_prec == "bf16":
+            eng_prec = os.environ.get("VLATOUCH_DINO_PRECISION", "fp16")
+        self.engine = DinoEngine(sd, heads=cfg["heads"], precision=eng_prec, device=device)
         self.model = self          # the reference exposes `.model` (eval / to / parameters are no-ops on frozen weights)
 
     # frozen-model conveniences the reference's callers touch

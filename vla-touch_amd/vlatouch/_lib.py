@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlatouch_hip.so")
 
-F32, BF16, F32X3 = 0, 1, 2   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only)
+F32, BF16, F32X3, F16 = 0, 1, 2, 3   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only); F16: IEEE half
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4
 NORM_LAYER, NORM_RMS_MEANSQ, NORM_RMS_VAR = 0, 1, 2
 IMGNORM_AUTO, IMGNORM_ON, IMGNORM_OFF = 0, 1, 2
@@ -171,11 +171,13 @@ def dt_code(dtype: torch.dtype) -> int:
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float16:
+        return F16
     raise VtError(f"unsupported dtype {dtype}")
 
 
 def torch_dtype(code: int) -> torch.dtype:
-    return torch.float32 if code == F32 else torch.bfloat16
+    return {F32: torch.float32, F32X3: torch.float32, BF16: torch.bfloat16, F16: torch.float16}[code]
 
 
 def ptr_array(tensors: Sequence[Optional[torch.Tensor]]):

@@ -29,7 +29,9 @@ def precision_dtypes(precision: str):
         return L.F32, L.F32
     if precision == "bf16":
         return L.BF16, L.BF16
-    raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+    if precision == "fp16":
+        return L.F16, L.F16
+    raise ValueError(f"precision must be 'fp32', 'bf16' or 'fp16', got {precision!r}")
 
 
 class _Workspace:
@@ -211,7 +213,7 @@ class DinoEngine:
         pw = g("embeddings.patch_embeddings.projection.weight")
         D = pw.shape[0]
         self.hidden, self.heads, self.patch = D, heads, patch
-        self.kpad = _pad_to(3 * patch * patch)
+        self.kpad = _pad_to(3 * patch * patch, 16 if cdt == L.F32 else 64)   # 16-bit: K % 64 keeps the patch GEMM on the LDS-DMA path
         layers = 0
         while f"encoder.layer.{layers}.norm1.weight" in sd:
             layers += 1
