@@ -156,3 +156,25 @@ def test_rdt_wide_batch_takes_large_gemm_path_with_fused_headnorm():
     e_hip, e_ref = err(y, exact.numpy()), err(ref16.float(), exact.numpy())
     print(f"[wide B4] scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |ref16-exact| {e_ref:.3e}")
     assert e_hip <= max(1e-2 * scale, 1.5 * e_ref), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("img_len", [70, 75, 128])
+def test_rdt_condition_cache_written_by_gemm_epilogues(img_len):
+    """B=12 makes the condition K/V projections (M = 12*img_len rows) take the large-GEMM path, whose epilogues write the
+    per-(batch, head) [K | Vt] tile stream directly: even / odd lengths exercise the aligned and the element-wise Vt stores,
+    partial last tiles and 4-key groups that straddle a batch or tile boundary."""
+    from oracle import rdt as orr
+    cfg = dict(cases.RDT_WIDE, img_cond_len=img_len)
+    m = make_rdt(cfg, torch.bfloat16)
+    ri = cases.rdt_inputs(cfg, 12, 20, seed=11, dtype=torch.bfloat16)
+    y = m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"])
+    sd = cases.rdt_sd(cfg, torch.bfloat16)
+    f32 = {k: v.float() for k, v in sd.items()}
+    rf = {k: (v.float() if v.is_floating_point() else v) for k, v in ri.items()}
+    exact = orr.rdt_forward(f32, rf["x"], rf["freq"], rf["t"], rf["lang_c"], rf["img_c"], lang_mask=rf["lang_mask"], heads=cfg["heads"], horizon=cfg["horizon"])
+    ref16 = orr.rdt_forward(sd, ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"], heads=cfg["heads"], horizon=cfg["horizon"])
+    scale = float(exact.abs().max())
+    e_hip, e_ref = err(y, exact.numpy()), err(ref16.float(), exact.numpy())
+    print(f"[img_len {img_len}] scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |ref16-exact| {e_ref:.3e}")
+    assert torch.isfinite(y.float()).all()
+    assert e_hip <= max(1e-2 * scale, 1.5 * e_ref), (e_hip, e_ref)

@@ -1,9 +1,13 @@
-// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT, bf16): K row-major [B][Lk][H*64] (after k_norm) and
-// V stored TRANSPOSED per head, Vt [B][H][64][Lpad] (Lpad % 64 == 0, padding zero-filled), written once per chunk by
-// vt_k_transpose_v and re-read by every denoise step.  With V already transposed both operand tiles are plain 128-byte
-// rows, so they go HBM -> LDS by DMA (global_load_lds_dwordx4, source-side XOR swizzle) into a 2-stage ring while the
-// previous tile's MFMAs run: the kernel streams the 1.15 GB of RDT-1B image K/V per call at HBM rate instead of
-// staging through registers with scalar LDS transposes (vt_attn.hip, still used for self-attention).
+// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT, bf16).  The cache is a per-(batch, head) TILE STREAM:
+//   tile(b, h, t) at KV + ((b*H + h)*T + t) * 8192 elements = [K: 64 keys x 64 d (after k_norm)][Vt: 64 d x 64 keys]
+//   (Vt keys in MFMA k order: key kk of the tile sits at position vt_kpos(kk), see vt_kernels.h)
+// i.e. 16 KiB contiguous per 64 keys, written once per chunk (straight from the K / V projection GEMM epilogues, or by the
+// retile kernels below for small shapes) and re-read by every denoise step.  Both halves are plain 128-byte rows, so a
+// tile goes HBM -> LDS by DMA (global_load_lds_dwordx4, source-side XOR swizzle) into a 2-stage ring while the previous
+// tile's MFMAs run: the kernel streams the 1.15 GB of RDT-1B image K/V per call in whole 16-KiB bursts instead of
+// 128-byte pieces strided by the row pitch, or staging through registers with scalar LDS transposes (vt_attn.hip, still
+// used for self-attention).  Rows of the last tile beyond Nk are never written by the GEMMs: keys are masked in the
+// softmax and the Vt fragment is zeroed there (0 * garbage could be NaN).
 // Block = NW waves = 16*NW query rows of one (batch, head); fragment conventions as vt_attn.hip.
 #include "vt_common.h"
 #include "vt_kernels.h"
@@ -24,8 +28,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
-  const bf16_t* K = reinterpret_cast<const bf16_t*>(p.K) + (long)b * p.k_bs + (long)h * 64;
-  const bf16_t* VT = reinterpret_cast<const bf16_t*>(p.VT) + ((long)b * p.H + h) * 64 * p.Lpad;
+  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + ((long)b * p.H + h) * p.T * 8192;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
 
   Frag<bf16_t> qf[2];
@@ -33,22 +36,17 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   for (int ks = 0; ks < 2; ++ks)
     qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
 
-  // DMA plan: 16 wave-instructions per tile (8 for K rows, 8 for Vt rows), instruction i handled by wave i % nw.
-  // lane -> (row = i8*8 + lane/8, chunk position = lane%8); it fetches the chunk whose swizzled position is its own.
+  // DMA plan: 16 wave-instructions per tile (8 for K rows, 8 for Vt rows = 16 x 1 KiB of the contiguous tile),
+  // instruction i handled by wave i % nw.  lane -> (row = i*8 + lane/8, chunk position = lane%8); it fetches the chunk
+  // whose swizzled position is its own.
   const int r_in = lane >> 3, pch = lane & 7;
   auto stage = [&](int buf, int tile) {
     char* base = smem + buf * STAGE;
-    const int key0 = tile * KT;
+    const bf16_t* src = KV + (long)tile * 8192;
     for (int i = wave; i < 16; i += nw) {
-      const int i8 = i & 7;
-      const int r = i8 * 8 + r_in;
+      const int r = (i & 7) * 8 + r_in;
       const int c = pch ^ ((r >> 1) & 7);
-      if (i < 8) {
-        const int key = min(key0 + r, p.Nk - 1);                     // clamped rows are masked in the softmax
-        __builtin_amdgcn_global_load_lds((glb_void*)(K + (long)key * p.k_rs + c * 8), (lds_void*)(base + i8 * 1024), 16, 0, 0);
-      } else {
-        __builtin_amdgcn_global_load_lds((glb_void*)(VT + (long)r * p.Lpad + key0 + c * 8), (lds_void*)(base + KT * 128 + i8 * 1024), 16, 0, 0);
-      }
+      __builtin_amdgcn_global_load_lds((glb_void*)(src + (i * 8 + r_in) * 64 + c * 8), (lds_void*)(base + i * 1024), 16, 0, 0);
     }
   };
 
@@ -56,6 +54,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  const float cscale = p.scale * 1.4426950408889634f;
 
   const int ntiles = (p.Nk + KT - 1) / KT;
   stage(0, 0);
@@ -78,49 +77,66 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
         mma16(sacc[kt], kf, qf[ks]);
       }
     }
+    // online softmax in the exp2 domain: p = exp2(s*c - m*c), c = scale*log2(e) (c > 0, so the max is taken on raw scores).
+    // Masking (partial last tile, key mask) is a block-uniform slow path; full unmasked tiles pay nothing for it.
     float sv[16];
-    float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kidx = key0 + kt * 16 + g * 4 + r;
-        bool ok = kidx < p.Nk;
-        if (ok && km) ok = km[kidx] != 0;
-        const float s = ok ? sacc[kt][r] * p.scale : -INFINITY;
-        sv[kt * 4 + r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
+    if (km || key0 + KT > p.Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kidx = key0 + kt * 16 + g * 4 + r;
+          bool ok = kidx < p.Nk;
+          if (ok && km) ok = km[kidx] != 0;
+          if (!ok) sv[kt * 4 + r] = -INFINITY;
+        }
+    }
+    float mx = sv[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+    if (__any(m_new != m_run)) {          // rescale only when some row's running max moved (rare after the first tiles)
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
     float psum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { sv[i] = __expf(sv[i] - m_use); psum += sv[i]; }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+    l_run += psum;
+    const bool partial = key0 + KT > p.Nk;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // P fragment = this lane's own scores: k index j <-> key kb*32 + (j>>2)*16 + g*4 + (j&3)
+      uint4 pw;
+      pw.x = pk_bf16(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
+      pw.y = pk_bf16(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
+      pw.z = pk_bf16(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
+      pw.w = pk_bf16(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
       Frag<bf16_t> pf;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) pf.v[j] = (short)f2bf(sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)]);
+      pf.v = __builtin_bit_cast(short8_t, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        // Vt row d = dt*16 + l15; keys kb*32 + g*4 .. +3 (8 B) and kb*32 + 16 + g*4 .. +3: chunk = key/8, half = g&1
-        const int row = dt * 16 + l15;
-        const int sw = (row >> 1) & 7;
-        const char* rp = Vs + row * 128 + (g & 1) * 8;
-        const uint2 lo = *reinterpret_cast<const uint2*>(rp + (((kb * 4 + (g >> 1)) ^ sw) << 4));
-        const uint2 hi = *reinterpret_cast<const uint2*>(rp + (((kb * 4 + 2 + (g >> 1)) ^ sw) << 4));
+        // the Vt tile stores its keys in the SAME k order (position g*8 + j inside each 32-key half), so the A fragment of
+        // row d = dt*16 + l15 is one 16-byte chunk
         Frag<bf16_t> vf;
-        vf.v[0] = (short)(lo.x & 0xffff); vf.v[1] = (short)(lo.x >> 16); vf.v[2] = (short)(lo.y & 0xffff); vf.v[3] = (short)(lo.y >> 16);
-        vf.v[4] = (short)(hi.x & 0xffff); vf.v[5] = (short)(hi.x >> 16); vf.v[6] = (short)(hi.y & 0xffff); vf.v[7] = (short)(hi.y >> 16);
+        lds_frag(vf, Vs, dt * 16 + l15, kb * 4 + g);
+        if (partial) {          // last, partial tile (block-uniform): unwritten keys must not reach the MFMA
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (key0 + kb * 32 + (j >> 2) * 16 + g * 4 + (j & 3) >= p.Nk) vf.v[j] = 0;
+        }
         mma16(o[dt], vf, pf);
       }
     }
@@ -135,15 +151,28 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint2 t;
-      t.x = (uint32_t)f2bf(o[dt][0] * inv) | ((uint32_t)f2bf(o[dt][1] * inv) << 16);
-      t.y = (uint32_t)f2bf(o[dt][2] * inv) | ((uint32_t)f2bf(o[dt][3] * inv) << 16);
+      t.x = pk_bf16(o[dt][0] * inv, o[dt][1] * inv);
+      t.y = pk_bf16(o[dt][2] * inv, o[dt][3] * inv);
       *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = t;
     }
   }
 }
 
-// V [B][L][ld] (head h at columns h*64..) -> Vt [B][H][64][Lpad], zero padded for l >= L.  One block per (64-token tile, h, b).
-__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ V, long ld, bf16_t* __restrict__ VT, int L, int Lpad, int H) {
+// small-shape fallbacks: row-major projections [B][L][ld] (head h at columns h*64..) -> the tile stream.
+// One block per (64-token tile, h, b).  K part: a row copy.
+__global__ __launch_bounds__(256) void retile_k_kernel(const bf16_t* __restrict__ Ksrc, long ld, bf16_t* __restrict__ KV, int L, int T, int H) {
+  const int b = blockIdx.z, h = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* src = Ksrc + (long)b * L * ld + (long)h * 64;
+  bf16_t* dst = KV + (((long)b * H + h) * T + t) * 8192;
+  for (int e = tid; e < 64 * 8; e += 256) {            // 64 tokens x 8 chunks of 8 d
+    const int r = e >> 3, c = e & 7, l = t * 64 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (l < L) v = *reinterpret_cast<const uint4*>(src + (long)l * ld + c * 8);
+    *reinterpret_cast<uint4*>(dst + r * 64 + c * 8) = v;
+  }
+}
+// Vt part: transpose through LDS, zero padded for l >= L.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ V, long ld, bf16_t* __restrict__ KV, int L, int T, int H) {
   __shared__ bf16_t tile[64][66];
   const int b = blockIdx.z, h = blockIdx.y, l0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
@@ -157,18 +186,18 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     for (int j = 0; j < 8; ++j) tile[c * 8 + j][t] = ve[j];
   }
   __syncthreads();
-  bf16_t* dst = VT + ((long)b * H + h) * 64 * Lpad + l0;
+  bf16_t* dst = KV + (((long)b * H + h) * T + blockIdx.x) * 8192 + 4096;
   for (int e = tid; e < 64 * 32; e += 256) {           // 64 d rows x 32 pairs of tokens
     const int d = e >> 5, t2 = (e & 31) * 2;
     const uint32_t v = (uint32_t)tile[d][t2] | ((uint32_t)tile[d][t2 + 1] << 16);
-    *reinterpret_cast<uint32_t*>(dst + (long)d * Lpad + t2) = v;
+    *reinterpret_cast<uint32_t*>(dst + d * 64 + vt_kpos(t2)) = v;
   }
 }
 
 }  // namespace
 
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
-  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.Lpad % 64 || p.Lpad < p.Nk || p.q_rs % 8 || p.k_rs % 8) return VT_ERR_ARG;
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.T * 64 < p.Nk || p.q_rs % 8) return VT_ERR_ARG;
   int nw = 4, best = 1 << 30;
   for (int w = 4; w <= 8; ++w) {
     const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
@@ -179,8 +208,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   return vt_check_launch();
 }
 
-int vt_k_transpose_v(const void* V, long ld, void* VT, int B, int L, int Lpad, int H, hipStream_t s) {
-  if (Lpad % 64 || Lpad < L || ld % 8) return VT_ERR_ARG;
-  hipLaunchKernelGGL(transpose_v_kernel, dim3(Lpad / 64, H, B), dim3(256), 0, s, (const bf16_t*)V, ld, (bf16_t*)VT, L, Lpad, H);
+int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int B, int L, int T, int H, hipStream_t s) {
+  if (T * 64 < L || ld % 8) return VT_ERR_ARG;
+  if (Ksrc) hipLaunchKernelGGL(retile_k_kernel, dim3(T, H, B), dim3(256), 0, s, (const bf16_t*)Ksrc, ld, (bf16_t*)KV, L, T, H);
+  if (Vsrc) hipLaunchKernelGGL(transpose_v_kernel, dim3(T, H, B), dim3(256), 0, s, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, L, T, H);
   return vt_check_launch();
 }

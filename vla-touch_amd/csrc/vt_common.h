@@ -27,12 +27,13 @@ enum { VT_F32 = 0, VT_BF16 = 1, VT_F32X3 = 2, VT_F16 = 3 };
 enum { VT_ACT_NONE = 0, VT_ACT_GELU_ERF = 1, VT_ACT_GELU_TANH = 2, VT_ACT_SILU = 3, VT_ACT_MISH = 4 };
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+typedef __attribute__((ext_vector_type(2))) float float2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// float -> bf16, round-to-nearest-even, NaN preserved: v_cvt_pk_bf16_f32 (one instruction per PAIR)
+__device__ __forceinline__ uint32_t pk_bf16(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){lo, hi}, bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
 __device__ __forceinline__ float h2f(half_t h) { return (float)__builtin_bit_cast(_Float16, h.b); }
 __device__ __forceinline__ half_t f2h(float f) { half_t r; r.b = __builtin_bit_cast(uint16_t, (_Float16)f); return r; }   // v_cvt_f16_f32: RNE, saturates to inf
 

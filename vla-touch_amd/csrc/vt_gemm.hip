@@ -324,7 +324,7 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.splitk < 1 || p.groups < 1) return VT_ERR_ARG;
   if (p.splitk > 1 && p.c_dtype != VT_F32) return VT_ERR_ARG;
   if (vt_gemm_fast_eligible(p)) return vt_gemm_fast_launch(p, s);     // large bf16 GEMMs: LDS-DMA pipeline (vt_gemm_fast.hip)
-  if (p.hn_w0 || p.hn_w1) return VT_ERR_UNSUPPORTED;                   // fused head-norm exists only on the fast path
+  if (p.hn_w0 || p.hn_w1 || p.cmap) return VT_ERR_UNSUPPORTED;         // fused head-norm / tile-stream output exist only on the fast path
   if (p.a_dtype == VT_BF16 && p.w_dtype == VT_BF16) {
     if (p.c_dtype == VT_BF16) return launch_cfg<bf16_t, bf16_t, bf16_t>(p, s);
     if (p.c_dtype == VT_F32) return launch_cfg<bf16_t, bf16_t, float>(p, s);

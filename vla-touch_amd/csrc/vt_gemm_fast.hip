@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include "vt_common.h"
 #include "vt_gemm.h"
+#include "vt_kernels.h"
 #include "vt_prof.h"
 
 int g_vt_gm = 0;         // m-tiles per super-row (VLATOUCH_GEMM_GM; 0 = choose per launch)
@@ -29,11 +30,12 @@ typedef const __attribute__((address_space(1))) void glb_void;
 
 constexpr int BN = 128, BK = 64;
 constexpr int EP_LD = 68;                      // floats per row of the epilogue patch (64 + 4 pad, keeps 16-B alignment)
-constexpr int EP_BYTES = 32 * EP_LD * 4;       // per-wave patch: 32 rows x 64 columns fp32
+constexpr int EPT_LD = 36;                     // transposed patch (cmap 2): 64 d-rows x 32 keys + 4 pad
+constexpr int EP_BYTES = 64 * EPT_LD * 4;      // per-wave patch: max(32 x EP_LD, 64 x EPT_LD) floats
 
 // NS = LDS stages: 2 = the DMA of k-tile t+1 overlaps the MFMAs of tile t inside the block (2 blocks/CU);
 //                 1 = no overlap inside a block, latency is hidden by MINW (3-4) co-resident blocks per CU instead.
-template <typename T16, typename TC, int BM, int NS, int MINW>
+template <typename T16, typename TC, int BM, int NS, int MINW, int CMAP>
 __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int TM = BM / 32;               // 16-row MFMA tiles per wave along M
@@ -175,7 +177,46 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
           if (cs) x *= cs[min(ncol0 + i * 16 + g * 4 + r, p.N - 1)];
           op[r] = x;
         }
-        *reinterpret_cast<float4*>(ep + (jj * 16 + l15) * EP_LD + i * 16 + g * 4) = o;
+        if constexpr (CMAP == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ep[(i * 16 + g * 4 + r) * EPT_LD + jj * 16 + l15] = op[r];
+        } else {
+          *reinterpret_cast<float4*>(ep + (jj * 16 + l15) * EP_LD + i * 16 + g * 4) = o;
+        }
+      }
+    }
+    if constexpr (sizeof(TC) == 2 && CMAP == 2) {
+      {
+        // Vt tiles: 8 lanes cover the 32 keys of one d row (64 B), 8 d rows per instruction.  A lane's 4 keys are
+        // consecutive rows m of the GEMM; they leave the fast path when they cross a batch or 64-key tile boundary.
+        const long hbase = (long)(ncol0 >> 6);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int dd = it * 8 + (lane >> 3), kq = (lane & 7) * 4;
+          const float4 x = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + kq);
+          const float o[4] = {x.x, x.y, x.z, x.w};
+          const int m = mrow0 + jp * 16 + kq;
+          if (m < p.M) {
+            const int bb = m / p.cmap_L, l = m - bb * p.cmap_L;
+            if (m + 3 < p.M && l + 3 < p.cmap_L && (l & 63) <= 60 && (l & 1) == 0) {
+              TC* dst = Cg + ((((long)bb * p.cmap_H + hbase) * p.cmap_T + (l >> 6)) * 2 + 1) * 4096 + dd * 64;
+              TC ov[4] = {Elem<TC>::from_f(o[0]), Elem<TC>::from_f(o[1]), Elem<TC>::from_f(o[2]), Elem<TC>::from_f(o[3])};
+              const uint32_t* ow = reinterpret_cast<const uint32_t*>(ov);
+              *reinterpret_cast<uint32_t*>(dst + vt_kpos(l & 63)) = ow[0];             // aligned key pairs stay adjacent in k order
+              *reinterpret_cast<uint32_t*>(dst + vt_kpos((l + 2) & 63)) = ow[1];
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int mm = m + e;
+                if (mm < p.M) {
+                  const int b2 = mm / p.cmap_L, l2 = mm - b2 * p.cmap_L;
+                  Cg[((((long)b2 * p.cmap_H + hbase) * p.cmap_T + (l2 >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(l2 & 63)] = Elem<TC>::from_f(o[e]);
+                }
+              }
+            }
+          }
+        }
+        continue;
       }
     }
     // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
@@ -186,6 +227,17 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
       const int m = mrow0 + jp * 16 + row, n = ncol0 + c4 * 4;
       if (m < p.M && n < p.N) {
         float o[4] = {x.x, x.y, x.z, x.w};
+        if constexpr (sizeof(TC) == 2 && CMAP == 1) {
+          {      // K tiles: the wave's 64 columns are one head's row of the tile
+            const int bb = m / p.cmap_L, l = m - bb * p.cmap_L;
+            TC ov[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ov[r] = Elem<TC>::from_f(o[r]);
+            *reinterpret_cast<uint2*>(Cg + ((((long)bb * p.cmap_H + (ncol0 >> 6)) * p.cmap_T + (l >> 6)) * 2) * 4096 + (l & 63) * 64 + c4 * 4) =
+                *reinterpret_cast<const uint2*>(ov);
+            continue;
+          }
+        }
         if constexpr (sizeof(TC) == 4) {
           if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
           *reinterpret_cast<float4*>(Cg + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
@@ -208,8 +260,8 @@ __global__ __launch_bounds__(256, MINW) void gemm_glds_kernel(const VtGemmParams
 
 }  // namespace
 
-int g_vt_force_bm = 0;   // tuning hooks: VLATOUCH_GEMM_BM=64|128, VLATOUCH_GEMM_VARIANT=22|13|14
-int g_vt_variant = 0;    // 0 = choose per launch
+int g_vt_force_bm = 0;   // tuning hooks: VLATOUCH_GEMM_BM=64|128, VLATOUCH_GEMM_VARIANT=22|14
+int g_vt_variant = 0;    // 0 = choose per launch; 22 = two LDS stages at 2 blocks/CU, 14 = one stage at 4 blocks/CU
 
 bool vt_gemm_fast_eligible(const VtGemmParams& p) {
   static const bool init = [] { const char* e = getenv("VLATOUCH_GEMM_BM"); if (e) g_vt_force_bm = atoi(e); e = getenv("VLATOUCH_GEMM_VARIANT"); if (e) g_vt_variant = atoi(e); e = getenv("VLATOUCH_GEMM_GM"); if (e) g_vt_gm = atoi(e); return true; }();
@@ -218,22 +270,20 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p) {
   if (p.c_dtype != p.a_dtype && p.c_dtype != VT_F32) return false;
   if (p.K % BK || p.lda % 8 || p.ldw % 8 || p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)) return false;
   if (p.M < 128) return false;
+  if (p.cmap && (p.a_dtype != VT_BF16 || p.c_dtype == VT_F32 || p.N % 64 || p.residual || p.groups != 1 || p.cmap_L <= 0 || p.cmap_T * 64 < p.cmap_L || p.M % p.cmap_L)) return false;
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + BN - 1) / BN) * p.groups;
   return tiles >= 96;
 }
 
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p) { return vt_gemm_fast_eligible(p) && (p.N % 64) == 0; }
 
-template <typename T16, typename TC, int BM>
+template <typename T16, typename TC, int BM, int CMAP>
 static void launch_variant(int variant, dim3 grid, hipStream_t s, const VtGemmParams& p, int tiles_n, int per_group, int total) {
   // super-row height (measured): tall-skinny outputs (few n-tiles, many m-tiles: the condition K/V projections) like 16,
   // everything else 4
   const int gm = g_vt_gm > 0 ? g_vt_gm : ((tiles_n <= 16 && per_group / tiles_n >= 128) ? 16 : 4);
-  switch (variant) {
-    case 13: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 1, 3>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
-    case 14: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 1, 4>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
-    default: hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 2, 2>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm); break;
-  }
+  if (variant == 14) hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 1, 4, CMAP>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm);
+  else hipLaunchKernelGGL((gemm_glds_kernel<T16, TC, BM, 2, 2, CMAP>), grid, dim3(256), 0, s, p, tiles_n, per_group, total, gm);
 }
 
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
@@ -246,11 +296,16 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   const int bm = (g_vt_force_bm == 64 || g_vt_force_bm == 128) ? g_vt_force_bm : (tiles128 < 1024 ? 64 : 128);
   const int tiles_m = (p.M + bm - 1) / bm;
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
-  const int variant = g_vt_variant ? g_vt_variant : (total < 768 ? 22 : 14);   // 22 = two stages, 2 blocks/CU; 13 / 14 = one stage, 3 / 4 blocks/CU
+  const int variant = g_vt_variant ? g_vt_variant : (total < 768 ? 22 : 14);   // 22 = two stages, 2 blocks/CU; 14 = one stage, 4 blocks/CU
   VtProfScope prof(true, p, s);
-#define VT_FAST_GO(T16, TC, BMv) launch_variant<T16, TC, BMv>(variant, dim3(total), s, p, tiles_n, per_group, total)
+#define VT_FAST_GO(T16, TC, BMv) launch_variant<T16, TC, BMv, 0>(variant, dim3(total), s, p, tiles_n, per_group, total)
+#define VT_FAST_GO_CMAP(BMv) \
+  { if (p.cmap == 1) launch_variant<bf16_t, bf16_t, BMv, 1>(variant, dim3(total), s, p, tiles_n, per_group, total); \
+    else launch_variant<bf16_t, bf16_t, BMv, 2>(variant, dim3(total), s, p, tiles_n, per_group, total); }
   const bool c16 = p.c_dtype != VT_F32;
-  if (p.a_dtype == VT_BF16) {
+  if (p.cmap) {
+    if (bm == 128) VT_FAST_GO_CMAP(128) else VT_FAST_GO_CMAP(64)
+  } else if (p.a_dtype == VT_BF16) {
     if (bm == 128) { if (c16) VT_FAST_GO(bf16_t, bf16_t, 128); else VT_FAST_GO(bf16_t, float, 128); }
     else           { if (c16) VT_FAST_GO(bf16_t, bf16_t, 64);  else VT_FAST_GO(bf16_t, float, 64); }
   } else {
@@ -258,5 +313,6 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
     else           { if (c16) VT_FAST_GO(half_t, half_t, 64);  else VT_FAST_GO(half_t, float, 64); }
   }
 #undef VT_FAST_GO
+#undef VT_FAST_GO_CMAP
   return vt_check_launch();
 }

@@ -29,18 +29,22 @@ struct VtAttnParams {
   int dtype;
 };
 
-// cross-attention against the cached condition: K [B][Nk][k_rs] (+h*64), Vt [B][H][64][Lpad] (bf16 only)
+// cross-attention against the cached condition (bf16 only): KV = per-(b, h) tile stream, see vt_attn_kvt.hip
 struct VtAttnKvtParams {
-  const void* Q; const void* K; const void* VT; void* O;
+  const void* Q; const void* KV; void* O;
   long q_bs, q_rs;            // Q element strides: batch, row (head h at +h*64)
-  long k_bs, k_rs;
   long o_bs, o_rs;
   const uint8_t* kmask;       // [B][Nk] or null
-  int B, H, Nq, Nk, Lpad;
+  int B, H, Nq, Nk, T;        // T = tiles of 64 keys per (b, h)
   float scale;
 };
+// position of key kk (0..63) inside a Vt tile row: within each 32-key half the keys are stored in the k order of the
+// P fragment (k index g*8 + j <-> key (j>>2)*16 + g*4 + (j&3)), so an A fragment of Vt is one 16-byte chunk.  Aligned pairs
+// and aligned groups of 4 keys stay contiguous.
+__host__ __device__ inline int vt_kpos(int kk) { return (kk & 32) | (((kk >> 2) & 3) << 3) | (((kk >> 4) & 1) << 2) | (kk & 3); }
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s);
-int vt_k_transpose_v(const void* V, long ld, void* VT, int B, int L, int Lpad, int H, hipStream_t s);
+// row-major K / V projections [B][L][ld] -> the tile stream (either source may be null)
+int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int B, int L, int T, int H, hipStream_t s);
 
 int vt_gemm_launch(const VtGemmParams& p, hipStream_t s);
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s);
