@@ -29,4 +29,6 @@ struct VtProfScope {
 
 bool vt_gemm_fast_eligible(const VtGemmParams& p);
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p);
+bool vt_gemm_pp_eligible(const VtGemmParams& p);          // vt_gemm_pp.hip: 256-square ping-pong tile
+int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s);
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s);
