@@ -33,8 +33,8 @@ template <> struct QLoad<float> {
 template <typename T> struct PackP;
 template <> struct PackP<bf16_t> {
   __device__ static __forceinline__ void pack(Frag<bf16_t>& f, const float p[8]) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) f.v[j] = (short)f2bf(p[j]);
+    const uint4 w = make_uint4(pk_bf16(p[0], p[1]), pk_bf16(p[2], p[3]), pk_bf16(p[4], p[5]), pk_bf16(p[6], p[7]));
+    f.v = __builtin_bit_cast(short8_t, w);
   }
 };
 template <> struct PackP<half_t> {
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
+  const float cscale = p.scale * 1.4426950408889634f;
 
   const int ntiles = (p.Nk + KT - 1) / KT;
   for (int tile = 0; tile < ntiles; ++tile) {
@@ -141,34 +142,44 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
         mma16(sacc[kt], kf, qf[ks]);
       }
     }
-    // ---- scale, mask, online softmax
+    // ---- online softmax in the exp2 domain: p = exp2(s*c - m*c), c = scale*log2(e) > 0 (the max is taken on raw scores);
+    // masking (partial last tile, key mask) is a block-uniform slow path
     float sv[16];
-    float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int kidx = key0 + kt * 16 + g * 4 + r;
-        bool ok = kidx < p.Nk;
-        if (ok && km) ok = km[kidx] != 0;
-        const float s = ok ? sacc[kt][r] * p.scale : -INFINITY;
-        sv[kt * 4 + r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
+    if (km || key0 + KT > p.Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kidx = key0 + kt * 16 + g * 4 + r;
+          bool ok = kidx < p.Nk;
+          if (ok && km) ok = km[kidx] != 0;
+          if (!ok) sv[kt * 4 + r] = -INFINITY;
+        }
+    }
+    float mx = sv[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : expf(m_run - m_use);
+    if (__any(m_new != m_run)) {          // rescale only when some row's running max moved
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
     float psum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { sv[i] = expf(sv[i] - m_use); psum += sv[i]; }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+    for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+    l_run += psum;
     // ---- O += P V   (two 32-key blocks)
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {

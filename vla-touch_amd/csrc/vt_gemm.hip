@@ -7,6 +7,7 @@
 // loads are issued before the current tile's MFMAs (software prefetch through registers).
 // Operands are swapped (D = W_tile * A_tile^T) so each lane ends with 4 CONSECUTIVE n for one m:
 // the epilogue reads bias/colscale/residual and writes C with 16-B (f32) / 8-B (bf16) vectors.
+#include <type_traits>
 #include "vt_common.h"
 #include "vt_gemm.h"
 #include "vt_prof.h"
@@ -250,6 +251,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
   const bool vec = ((p.ldc & 3) == 0) && ((p.N & 3) == 0) && (p.residual == nullptr || (p.ldr & 3) == 0);
   const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
   const float* cs = p.colscale;
+  // two copies of the store loop: the activation math inlined at every accumulator register is large, and jumping over it
+  // register by register costs an instruction-cache miss each time; the common case (no activation) gets a compact copy
+  auto store_all = [&](auto with_act) {
 #pragma unroll
   for (int j = 0; j < TM; ++j) {
     const int m = m0 + wm * TM * 16 + j * 16 + l15;
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
         const int nn = min(n + r, p.N - 1);
         float x = v[r];
         if (bias) x += bias[nn];
-        x = act_apply(x, p.act);
+        if constexpr (decltype(with_act)::value) x = act_apply(x, p.act);
         if (cs) x *= cs[nn];
         v[r] = x + rv[r];
       }
@@ -288,6 +292,9 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
         for (int r = 0; r < 4; ++r) if (n + r < p.N) C[r] = Elem<TC>::from_f(v[r]);
     }
   }
+  };
+  if (p.act == VT_ACT_NONE || raw) store_all(std::false_type{});
+  else store_all(std::true_type{});
 }
 
 template <typename TA, typename TW, typename TC>
