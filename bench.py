@@ -10,8 +10,9 @@ denormalised refined chunks [B, T, 10].  Inputs are resident in HBM before the t
 noise is drawn on device inside the step (as the reference does).  Episodes are independent: ranks take disjoint
 batches (weak scaling), frozen weights are broadcast once from rank 0 over RCCL, no collective in the step loop.
 
-Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` (dominant kernel = the 128x128-tile bf16
-MFMA GEMM, timed live with HIP events on its launch stream) and `cpu_baseline` (the oracle on the host cores).
+Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` (dominant kernel = gemm_pp256_kernel, the
+256-square ping-pong MFMA GEMM tile, timed live with HIP events on its launch stream; `roofline_other` carries the same
+figures for the 128-column GEMM kernel) and `cpu_baseline` (the oracle on the host cores).
 """
 from __future__ import annotations
 
@@ -201,12 +202,15 @@ def main():
 
         # ---- roofline leg: one eager step with HIP events around every launch of the dominant GEMM kernel
         lib = L.lib()
-        lib.vt_prof_enable(1)
-        step()
-        stream.synchronize()
-        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
-        L.check(lib.vt_prof_collect(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "vt_prof_collect")
-        lib.vt_prof_enable(0)
+        prof = {}
+        for mode in (2, 3):          # 2 = gemm_pp256_kernel, 3 = gemm_glds_kernel (separate eager steps: one event pool)
+            lib.vt_prof_enable(mode)
+            step()
+            stream.synchronize()
+            ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_long()
+            L.check(lib.vt_prof_collect(C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "vt_prof_collect")
+            lib.vt_prof_enable(0)
+            prof[mode] = (ms.value, fl.value, by.value, n.value)
 
     if dist is not None:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -235,20 +239,29 @@ def main():
         "config": {
             "workload": WL[1],
             "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "parallelism": f"dp{world} (episodes sharded, no step collectives)",
-            "hipgraph": graph is not None, "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
+            "hipgraph": graph is not None, "rdt_mode": "bf16 storage + bf16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32",
+            "dino_mode": "IEEE fp16 storage + f16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32", "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
             "weights": "random-init synthetic of the named architectures (no checkpoints offline; RDT-1B hyper-parameters are upstream's, "
                        "not in the reference)", "setup_s": round(setup_s, 1),
         },
     }
-    if n.value > 0 and ms.value > 0:
-        tf = fl.value / (ms.value * 1e-3) / 1e12
-        res["roofline"] = {
-            "kernel": "gemm_kernel<bf16,bf16,*,2,2,4,4> (128x128x64-tile bf16 MFMA GEMM: every large Linear of RDT / DINOv2)",
-            "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4),
-            "launches_per_step": n.value, "avg_launch_us": round(1000 * ms.value / n.value, 2),
-            "algorithmic_gflop_per_step": round(fl.value / 1e9, 1), "algorithmic_gbytes_per_step": round(by.value / 1e9, 3),
-            "share_of_step_time": round(ms.value / (1000 * elapsed / args.steps), 3), "traffic": None,
-        }
+    def roof(mode, name):
+        ms_, fl_, by_, n_ = prof[mode]
+        if n_ <= 0 or ms_ <= 0:
+            return None
+        tf = fl_ / (ms_ * 1e-3) / 1e12
+        return {"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2),
+                "algorithmic_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
+                "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3), "traffic": None}
+    r_pp = roof(2, "gemm_pp256_kernel (256x256x64 ping-pong tile, 16-bit MFMA: condition K/V projections, image adaptor, DINOv2 Linears)")
+    r_gl = roof(3, "gemm_glds_kernel (64/128 x 128 x 64 LDS-DMA tiles, 16-bit MFMA: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
+    if r_pp is not None:
+        res["roofline"] = r_pp
+        if r_gl is not None:
+            res["roofline_other"] = [r_gl]
+    elif r_gl is not None:
+        res["roofline"] = r_gl
 
     # ---- CPU baseline: the oracle (fp32 torch ops on the host cores), rank 0, N=1 only, on a BOUNDED sample:
     #      pi_I leg on CB episodes; RDT leg on ONE episode (the reference's own schedule: K/V re-projected every step).

@@ -33,9 +33,10 @@ int vt_version(void);
 /* MFMA fragment-layout self test (A = I with asymmetric B, both dtypes); out_err[2] device floats. */
 int vt_selftest_mfma(float* out_err, vt_stream_t stream);
 
-/* Live timing of the dominant kernel class (the 128x128-tile bf16 MFMA GEMM): while enabled, every launch of that
- * kernel is bracketed by HIP events on its launch stream.  vt_prof_collect (after the caller synchronised the
- * stream) returns the summed duration, the algorithmic FLOPs / bytes of those launches and their count. */
+/* Live timing of the LDS-DMA MFMA GEMM kernels: while enabled, every launch of the selected kernel is bracketed by HIP
+ * events on its launch stream.  on = 0 off, 1 both kernels, 2 only gemm_pp256_kernel (256-square ping-pong tile),
+ * 3 only gemm_glds_kernel (128-column tiles).  vt_prof_collect (after the caller synchronised the stream) returns the
+ * summed duration, the algorithmic FLOPs / bytes of those launches and their count. */
 int vt_prof_enable(int on);
 int vt_prof_collect(double* total_ms, double* flops, double* bytes, long* launches);
 

@@ -353,6 +353,7 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
 // ---- profiling control (exported through include/vlatouch.h)
 extern "C" int vt_prof_enable(int on) {
   g_vt_prof.on = on != 0;
+  g_vt_prof.mode = on > 1 ? on : 1;
   if (on) { g_vt_prof.used = 0; g_vt_prof.flops = 0.0; g_vt_prof.bytes = 0.0; }
   return VT_OK;
 }

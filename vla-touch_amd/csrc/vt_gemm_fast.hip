@@ -173,7 +173,7 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   const int tiles_n = (p.N + bn - 1) / bn, tiles_m = (p.M + bm - 1) / bm;
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
   const int variant = g_vt_variant ? g_vt_variant : (total < 768 ? 22 : 14);   // 22 = two stages, 2 blocks/CU; 14 = one stage, 4 blocks/CU
-  VtProfScope prof(true, p, s);
+  VtProfScope prof(3, p, s);
 #define VT_FAST_GO(T16, TC, BMv) launch_variant<T16, TC, BMv, 0>(variant, dim3(total), s, p, tiles_n, per_group, total)
 #define VT_FAST_GO3(T16, TC) \
   { if (bm == 128) VT_FAST_GO(T16, TC, 128); else VT_FAST_GO(T16, TC, 64); }

@@ -61,7 +61,12 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const VtGemmParams p
   //   A units (U0: sel 0, U3: sel 1): rows with (r & 64) == sel*64 -> r = (q>>3)*128 + sel*64 + (q&7)*8 + lane/8
   //   B units (U1: sel 0, U2: sel 1): rows with (r & 32) == sel*32 -> r = (q>>2)*64  + sel*32 + (q&3)*8 + lane/8
   // lane -> (row, chunk position); it fetches the chunk whose swizzled position is its own.  Rows beyond M / N are clamped.
-  const uint16_t* src[4][2];
+  // The pieces are buffer loads (SGPR resource of the tile's A / W row block + one 32-bit VGPR offset per lane + the k offset in
+  // an SGPR): the per-piece issue cost of the LDS-DMA is what bounds this kernel, and a 32-bit offset is half the address traffic
+  // of a 64-bit flat pointer per lane.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)(W + (long)n0 * p.ldw), 0, 0x7fffffff, 0x00020000);
+  int src[4][2];
   int dst[4][2];
 #pragma unroll
   for (int u = 0; u < 4; ++u)
@@ -73,13 +78,13 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const VtGemmParams p
       const int r8 = isA ? ((q >> 3) * 128 + sel * 64 + (q & 7) * 8) : ((q >> 2) * 64 + sel * 32 + (q & 3) * 8);
       const int r = r8 + (lane >> 3);
       const int c = (lane & 7) ^ ((r >> 1) & 7);
-      src[u][e] = isA ? A + (long)min(m0 + r, p.M - 1) * p.lda + c * 8 : W + (long)min(n0 + r, p.N - 1) * p.ldw + c * 8;
+      src[u][e] = isA ? (int)(((long)(min(m0 + r, p.M - 1) - m0) * p.lda + c * 8) * 2) : (int)(((long)(min(n0 + r, p.N - 1) - n0) * p.ldw + c * 8) * 2);
       dst[u][e] = (isA ? 0 : BM * 128) + r8 * 128;
     }
   auto stage = [&](int u, int buf, int kt) {
 #pragma unroll
     for (int e = 0; e < 2; ++e)
-      __builtin_amdgcn_global_load_lds((glb_void*)(src[u][e] + (long)kt * BK), (lds_void*)(smem + buf * BUF_BYTES + dst[u][e]), 16, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds((u == 0 || u == 3) ? rsA : rsW, (lds_void*)(smem + buf * BUF_BYTES + dst[u][e]), 16, src[u][e], kt * (BK * 2), 0, 0);
   };
 
   float4_t acc[4][8];
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const VtGemmParams p
 bool vt_gemm_pp_eligible(const VtGemmParams& p) {
   if (!vt_gemm_fast_eligible(p)) return false;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.groups;
+  if (p.lda >= (1 << 21) || p.ldw >= (1 << 21) || p.K >= (1 << 24)) return false;   // 32-bit buffer offsets inside a 256-row block
   return tiles256 >= 512 && p.K >= 512;            // at least two rounds of 256-square tiles over the 256 CUs
 }
 
@@ -167,7 +173,7 @@ int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s) {
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
   const int gm = g_vt_gm > 0 ? g_vt_gm : 8;
-  VtProfScope prof(true, p, s);
+  VtProfScope prof(2, p, s);
 #define VT_PP_GO(T16, TC, CM) hipLaunchKernelGGL((gemm_pp256_kernel<T16, TC, CM>), dim3(total), dim3(512), 0, s, p, tiles_n, per_group, total, gm)
   const bool c16 = p.c_dtype != VT_F32;
   if (p.cmap == 1) VT_PP_GO(bf16_t, bf16_t, 1);
