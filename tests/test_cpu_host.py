@@ -46,7 +46,7 @@ def test_ctypes_structs_match_c_layout():
 #include "vt_kernels.h"
 #include "../../include/vlatouch.h"
 int main() {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(VtGemmParams), offsetof(VtGemmParams, cmap_H), sizeof(VtGnParams), sizeof(VtAttnParams),
+  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(VtGemmParams), offsetof(VtGemmParams, cmap_T), sizeof(VtGnParams), sizeof(VtAttnParams),
          sizeof(vt_unet_desc), sizeof(vt_dino_desc), sizeof(vt_rdt_desc));
   return 0;
 }'''
@@ -60,7 +60,7 @@ int main() {
         pytest.skip("hipcc host probe did not build: " + r.stderr[-300:])
     out = subprocess.run([exe], capture_output=True, text=True).stdout.split()
     got = [int(x) for x in out]
-    want = [C.sizeof(_lib.GemmParams), _lib.GemmParams.cmap_H.offset, C.sizeof(_lib.GnParams), C.sizeof(_lib.AttnParams), C.sizeof(_lib.UnetDesc),
+    want = [C.sizeof(_lib.GemmParams), _lib.GemmParams.cmap_T.offset, C.sizeof(_lib.GnParams), C.sizeof(_lib.AttnParams), C.sizeof(_lib.UnetDesc),
             C.sizeof(_lib.DinoDesc), C.sizeof(_lib.RdtDesc)]
     assert got == want, (got, want)
 

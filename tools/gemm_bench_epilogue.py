@@ -6,16 +6,17 @@ import torch
 from vlatouch import ops
 dev = torch.device("cuda:0")
 B, Lc, D, H = 32, 4374, 2048, 32
-M, T = B * Lc, (Lc + 63) // 64
+M = B * Lc
+T = (M + 63) // 64
 a = torch.randn(M, D, device=dev).to(torch.bfloat16)
 w = (torch.randn(D, D, device=dev) * D ** -0.5).to(torch.bfloat16)
 bias = torch.randn(D, device=dev)
 g = torch.randn(64, device=dev)
 out = torch.empty(M, D, device=dev, dtype=torch.bfloat16)
-kv = torch.empty(B, H, T, 2, 64, 64, device=dev, dtype=torch.bfloat16)
+kv = torch.empty(H, T, 2, 64, 64, device=dev, dtype=torch.bfloat16)
 hn = (g, D, None, D, 1e-6, 1)
 cases = {"plain": dict(out=out), "bias": dict(out=out, bias=bias), "bias+headnorm": dict(out=out, bias=bias, headnorm=hn),
-         "bias+headnorm+cmap1": dict(out=kv, bias=bias, headnorm=hn, cmap=(1, Lc, T, H)), "bias+cmap2": dict(out=kv, bias=bias, cmap=(2, Lc, T, H))}
+         "bias+headnorm+cmap1": dict(out=kv, bias=bias, headnorm=hn, cmap=(1, T)), "bias+cmap2": dict(out=kv, bias=bias, cmap=(2, T))}
 for name, kw in cases.items():
     kw = dict(kw)
     b = kw.pop("bias", None)

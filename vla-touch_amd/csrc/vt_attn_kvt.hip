@@ -1,13 +1,14 @@
-// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT, bf16).  The cache is a per-(batch, head) TILE STREAM:
-//   tile(b, h, t) at KV + ((b*H + h)*T + t) * 8192 elements = [K: 64 keys x 64 d (after k_norm)][Vt: 64 d x 64 keys]
-//   (Vt keys in MFMA k order: key kk of the tile sits at position vt_kpos(kk), see vt_kernels.h)
-// i.e. 16 KiB contiguous per 64 keys, written once per chunk (straight from the K / V projection GEMM epilogues, or by the
-// retile kernels below for small shapes) and re-read by every denoise step.  Both halves are plain 128-byte rows, so a
-// tile goes HBM -> LDS by DMA (global_load_lds_dwordx4, source-side XOR swizzle) into a 2-stage ring while the previous
-// tile's MFMAs run: the kernel streams the 1.15 GB of RDT-1B image K/V per call in whole 16-KiB bursts instead of
-// 128-byte pieces strided by the row pitch, or staging through registers with scalar LDS transposes (vt_attn.hip, still
-// used for self-attention).  Rows of the last tile beyond Nk are never written by the GEMMs: keys are masked in the
-// softmax and the Vt fragment is zeroed there (0 * garbage could be NaN).
+// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT, bf16).  The cache is a per-head TILE STREAM over the rows
+// m = b*L + l of the whole batch (samples back to back):
+//   tile(h, t = m/64) at KV + (h*T + t) * 8192 elements = [K: 64 rows x 64 d (after k_norm)][Vt: 64 d x 64 rows]
+//   (Vt keys in MFMA k order: row kk of the tile sits at position vt_kpos(kk), see vt_kernels.h)
+// i.e. 16 KiB contiguous per 64 keys, written once per chunk straight from the K / V projection GEMM epilogues (whose 32-row
+// patches are exactly half tiles: aligned 8-byte stores, no per-sample bookkeeping in the GEMM) or by the retile kernels below
+// for small shapes, and re-read by every denoise step.  Sample b attends to rows [b*L, (b+1)*L): its first and last tile may
+// also hold a neighbour's keys (or never-written rows past the end), which are masked in the softmax and zeroed in the Vt
+// fragment (0 * garbage could be NaN).  Both halves of a tile are plain 128-byte rows, so a tile goes HBM -> LDS by DMA
+// (global_load_lds_dwordx4, source-side XOR swizzle) into a 2-stage ring while the previous tile's MFMAs run: the kernel streams
+// the 1.15 GB of RDT-1B image K/V per call in whole 16-KiB bursts (vt_attn.hip, register-staged, still serves self-attention).
 // Block = NW waves = 16*NW query rows of one (batch, head); fragment conventions as vt_attn.hip.
 #include "vt_common.h"
 #include "vt_kernels.h"
@@ -28,8 +29,10 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
-  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + ((long)b * p.H + h) * p.T * 8192;
+  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + (long)h * p.T * 8192;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
+  const int row0 = b * p.Nk, row1 = row0 + p.Nk;             // this sample's rows of the stream
+  const int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
 
   Frag<bf16_t> qf[2];
 #pragma unroll
@@ -56,15 +59,15 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   float m_run = -INFINITY, l_run = 0.f;
   const float cscale = p.scale * 1.4426950408889634f;
 
-  const int ntiles = (p.Nk + KT - 1) / KT;
-  stage(0, 0);
+  stage(0, t_first);
   __syncthreads();
-  for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
-    if (tile + 1 < ntiles) stage(cur ^ 1, tile + 1);
+  for (int tile = t_first; tile <= t_last; ++tile) {
+    const int cur = (tile - t_first) & 1;
+    if (tile < t_last) stage(cur ^ 1, tile + 1);
     const char* Ks = smem + cur * STAGE;
     const char* Vs = Ks + KT * 128;
-    const int key0 = tile * KT;
+    const int key0 = tile * KT;                               // stream row of the tile's first key
+    const bool partial = key0 < row0 || key0 + KT > row1;     // block-uniform
 
     float4_t sacc[4];
 #pragma unroll
@@ -84,14 +87,14 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
-    if (km || key0 + KT > p.Nk) {
+    if (km || partial) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int kidx = key0 + kt * 16 + g * 4 + r;
-          bool ok = kidx < p.Nk;
-          if (ok && km) ok = km[kidx] != 0;
+          bool ok = kidx >= row0 && kidx < row1;
+          if (ok && km) ok = km[kidx - row0] != 0;
           if (!ok) sv[kt * 4 + r] = -INFINITY;
         }
     }
@@ -115,7 +118,6 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
 #pragma unroll
     for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
     l_run += psum;
-    const bool partial = key0 + KT > p.Nk;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       // P fragment = this lane's own scores: k index j <-> key kb*32 + (j>>2)*16 + g*4 + (j&3)
@@ -132,10 +134,12 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
         // row d = dt*16 + l15 is one 16-byte chunk
         Frag<bf16_t> vf;
         lds_frag(vf, Vs, dt * 16 + l15, kb * 4 + g);
-        if (partial) {          // last, partial tile (block-uniform): unwritten keys must not reach the MFMA
+        if (partial) {          // first / last tile of the sample: rows that are not its keys must not reach the MFMA
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (key0 + kb * 32 + (j >> 2) * 16 + g * 4 + (j & 3) >= p.Nk) vf.v[j] = 0;
+          for (int j = 0; j < 8; ++j) {
+            const int kidx = key0 + kb * 32 + (j >> 2) * 16 + g * 4 + (j & 3);
+            if (kidx < row0 || kidx >= row1) vf.v[j] = 0;
+          }
         }
         mma16(o[dt], vf, pf);
       }
@@ -158,36 +162,36 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   }
 }
 
-// small-shape fallbacks: row-major projections [B][L][ld] (head h at columns h*64..) -> the tile stream.
-// One block per (64-token tile, h, b).  K part: a row copy.
-__global__ __launch_bounds__(256) void retile_k_kernel(const bf16_t* __restrict__ Ksrc, long ld, bf16_t* __restrict__ KV, int L, int T, int H) {
-  const int b = blockIdx.z, h = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
-  const bf16_t* src = Ksrc + (long)b * L * ld + (long)h * 64;
-  bf16_t* dst = KV + (((long)b * H + h) * T + t) * 8192;
-  for (int e = tid; e < 64 * 8; e += 256) {            // 64 tokens x 8 chunks of 8 d
-    const int r = e >> 3, c = e & 7, l = t * 64 + r;
+// small-shape fallbacks: row-major projections [M][ld] (head h at columns h*64..) -> the tile stream.  One block per (tile, h).
+// K part: a row copy.
+__global__ __launch_bounds__(256) void retile_k_kernel(const bf16_t* __restrict__ Ksrc, long ld, bf16_t* __restrict__ KV, int M, int T) {
+  const int h = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  const bf16_t* src = Ksrc + (long)h * 64;
+  bf16_t* dst = KV + ((long)h * T + t) * 8192;
+  for (int e = tid; e < 64 * 8; e += 256) {            // 64 rows x 8 chunks of 8 d
+    const int r = e >> 3, c = e & 7, m = t * 64 + r;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (l < L) v = *reinterpret_cast<const uint4*>(src + (long)l * ld + c * 8);
+    if (m < M) v = *reinterpret_cast<const uint4*>(src + (long)m * ld + c * 8);
     *reinterpret_cast<uint4*>(dst + r * 64 + c * 8) = v;
   }
 }
-// Vt part: transpose through LDS, zero padded for l >= L.
-__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ V, long ld, bf16_t* __restrict__ KV, int L, int T, int H) {
+// Vt part: transpose through LDS, zero padded for m >= M.
+__global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restrict__ V, long ld, bf16_t* __restrict__ KV, int M, int T) {
   __shared__ bf16_t tile[64][66];
-  const int b = blockIdx.z, h = blockIdx.y, l0 = blockIdx.x * 64;
+  const int h = blockIdx.y, m0 = blockIdx.x * 64;
   const int tid = threadIdx.x;
-  const bf16_t* src = V + (long)b * L * ld + (long)h * 64;
-  for (int e = tid; e < 64 * 8; e += 256) {            // 64 tokens x 8 chunks of 8 d
+  const bf16_t* src = V + (long)h * 64;
+  for (int e = tid; e < 64 * 8; e += 256) {            // 64 rows x 8 chunks of 8 d
     const int t = e >> 3, c = e & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (l0 + t < L) v = *reinterpret_cast<const uint4*>(src + (long)(l0 + t) * ld + c * 8);
+    if (m0 + t < M) v = *reinterpret_cast<const uint4*>(src + (long)(m0 + t) * ld + c * 8);
     const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
 #pragma unroll
     for (int j = 0; j < 8; ++j) tile[c * 8 + j][t] = ve[j];
   }
   __syncthreads();
-  bf16_t* dst = KV + (((long)b * H + h) * T + blockIdx.x) * 8192 + 4096;
-  for (int e = tid; e < 64 * 32; e += 256) {           // 64 d rows x 32 pairs of tokens
+  bf16_t* dst = KV + ((long)h * T + blockIdx.x) * 8192 + 4096;
+  for (int e = tid; e < 64 * 32; e += 256) {           // 64 d rows x 32 pairs of keys
     const int d = e >> 5, t2 = (e & 31) * 2;
     const uint32_t v = (uint32_t)tile[d][t2] | ((uint32_t)tile[d][t2 + 1] << 16);
     *reinterpret_cast<uint32_t*>(dst + d * 64 + vt_kpos(t2)) = v;
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }  // namespace
 
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
-  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || p.T * 64 < p.Nk || p.q_rs % 8) return VT_ERR_ARG;
+  if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || (long)p.T * 64 < (long)p.B * p.Nk || p.q_rs % 8) return VT_ERR_ARG;
   int nw = 4, best = 1 << 30;
   for (int w = 4; w <= 8; ++w) {
     const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
@@ -208,9 +212,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   return vt_check_launch();
 }
 
-int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int B, int L, int T, int H, hipStream_t s) {
-  if (T * 64 < L || ld % 8) return VT_ERR_ARG;
-  if (Ksrc) hipLaunchKernelGGL(retile_k_kernel, dim3(T, H, B), dim3(256), 0, s, (const bf16_t*)Ksrc, ld, (bf16_t*)KV, L, T, H);
-  if (Vsrc) hipLaunchKernelGGL(transpose_v_kernel, dim3(T, H, B), dim3(256), 0, s, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, L, T, H);
+int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int M, int T, int H, hipStream_t s) {
+  if ((long)T * 64 < M || ld % 8) return VT_ERR_ARG;
+  if (Ksrc) hipLaunchKernelGGL(retile_k_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Ksrc, ld, (bf16_t*)KV, M, T);
+  if (Vsrc) hipLaunchKernelGGL(transpose_v_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, M, T);
   return vt_check_launch();
 }

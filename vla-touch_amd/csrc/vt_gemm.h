@@ -28,8 +28,8 @@ struct VtGemmParams {
   int hn_c0_end, hn_c1_end;
   float hn_eps; int hn_mode;
   // output mapping of the cached-condition K / V projections (large-GEMM path, 16-bit C, N % 64 == 0, no residual):
-  // row m = b*cmap_L + l, column n = h*64 + d go to the per-(b, h) tile stream of vt_attn_kvt.hip,
-  //   tile(b, h, t = l/64) = C + (((b*cmap_H + h)*cmap_T + t) * 2) * 4096 elements:  [K: 64 keys x 64 d][Vt: 64 d x 64 keys]
-  // cmap 0 = plain row-major C; 1 = K part (rows of 64 d); 2 = Vt part (written transposed from the epilogue patch).
-  int cmap, cmap_L, cmap_T, cmap_H;
+  // row m (all samples of the batch back to back), column n = h*64 + d go to the per-head tile stream of vt_attn_kvt.hip,
+  //   tile(h, t = m/64) = C + ((h*cmap_T + t) * 2) * 4096 elements:  [K: 64 rows x 64 d][Vt: 64 d x 64 rows in MFMA k order]
+  // cmap 0 = plain row-major C; 1 = K part; 2 = Vt part (written transposed from the epilogue patch).  cmap_T = ceil(M/64).
+  int cmap, cmap_T;
 };

@@ -37,11 +37,10 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
   o[0] *= cs4.x; o[1] *= cs4.y; o[2] *= cs4.z; o[3] *= cs4.w;
   if (m >= p.M || !col_ok) return;
   if constexpr (sizeof(TC) == 2 && CMAP == 1) {      // K tiles: the wave's 64 columns are one head's row of the tile
-    const int bb = m / p.cmap_L, l = m - bb * p.cmap_L;
     TC ov[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ov[r] = Elem<TC>::from_f(o[r]);
-    *reinterpret_cast<uint2*>(Cg + ((((long)bb * p.cmap_H + (ncol0 >> 6)) * p.cmap_T + (l >> 6)) * 2) * 4096 + (l & 63) * 64 + (n - ncol0)) =
+    *reinterpret_cast<uint2*>(Cg + (((long)(ncol0 >> 6) * p.cmap_T + (m >> 6)) * 2) * 4096 + (m & 63) * 64 + (n - ncol0)) =
         *reinterpret_cast<const uint2*>(ov);
   } else if constexpr (sizeof(TC) == 4) {
     if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
@@ -94,34 +93,21 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
         }
       }
     if constexpr (sizeof(TC) == 2 && CMAP == 2) {
-      // Vt tiles (bias only): 8 lanes cover the 32 keys of one d row (64 B), 8 d rows per instruction.  A lane's 4 keys are
-      // consecutive rows m of the GEMM; they leave the fast path when they cross a batch or 64-key tile boundary.
-      const long hbase = (long)(ncol0 >> 6);
+      // Vt tiles (bias only): 8 lanes cover the patch's 32 rows (= 32 keys, half a tile) of one d row as one 64-byte segment,
+      // 8 d rows per instruction; a lane's 4 keys are an aligned group, contiguous in the tile's k order (vt_kpos).
+      const long tbase = (long)(ncol0 >> 6) * p.cmap_T;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int dd = it * 8 + (lane >> 3), kq = (lane & 7) * 4;
         const float4 x = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + kq);
         const float bv = bias ? bias[ncol0 + dd] : 0.f;
-        const float o[4] = {x.x + bv, x.y + bv, x.z + bv, x.w + bv};
         const int m = mrow0 + jp * 16 + kq;
         if (m < p.M) {
-          const int bb = m / p.cmap_L, l = m - bb * p.cmap_L;
-          if (m + 3 < p.M && l + 3 < p.cmap_L && (l & 63) <= 60 && (l & 1) == 0) {
-            TC* dst = Cg + ((((long)bb * p.cmap_H + hbase) * p.cmap_T + (l >> 6)) * 2 + 1) * 4096 + dd * 64;
-            TC ov[4] = {Elem<TC>::from_f(o[0]), Elem<TC>::from_f(o[1]), Elem<TC>::from_f(o[2]), Elem<TC>::from_f(o[3])};
-            const uint32_t* ow = reinterpret_cast<const uint32_t*>(ov);
-            *reinterpret_cast<uint32_t*>(dst + vt_kpos(l & 63)) = ow[0];             // aligned key pairs stay adjacent in k order
-            *reinterpret_cast<uint32_t*>(dst + vt_kpos((l + 2) & 63)) = ow[1];
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int mm = m + e;
-              if (mm < p.M) {
-                const int b2 = mm / p.cmap_L, l2 = mm - b2 * p.cmap_L;
-                Cg[((((long)b2 * p.cmap_H + hbase) * p.cmap_T + (l2 >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(l2 & 63)] = Elem<TC>::from_f(o[e]);
-              }
-            }
-          }
+          TC* dst = Cg + ((tbase + (m >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(m & 63);
+          TC ov[4] = {Elem<TC>::from_f(x.x + bv), Elem<TC>::from_f(x.y + bv), Elem<TC>::from_f(x.z + bv), Elem<TC>::from_f(x.w + bv)};
+          if (m + 3 < p.M) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(ov);
+          else
+            for (int e = 0; e < 4; ++e) if (m + e < p.M) dst[e] = ov[e];
         }
       }
     } else {

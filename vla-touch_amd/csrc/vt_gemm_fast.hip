@@ -143,7 +143,7 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p) {
   if (p.c_dtype != p.a_dtype && p.c_dtype != VT_F32) return false;
   if (p.K % BK || p.lda % 8 || p.ldw % 8 || p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)) return false;
   if (p.M < 128) return false;
-  if (p.cmap && (p.a_dtype != VT_BF16 || p.c_dtype == VT_F32 || p.N % 64 || p.residual || p.groups != 1 || p.cmap_L <= 0 || p.cmap_T * 64 < p.cmap_L || p.M % p.cmap_L)) return false;
+  if (p.cmap && (p.a_dtype != VT_BF16 || p.c_dtype == VT_F32 || p.N % 64 || p.residual || p.groups != 1 || (long)p.cmap_T * 64 < p.M)) return false;
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
   return tiles >= 96;
 }

@@ -29,13 +29,13 @@ struct VtAttnParams {
   int dtype;
 };
 
-// cross-attention against the cached condition (bf16 only): KV = per-(b, h) tile stream, see vt_attn_kvt.hip
+// cross-attention against the cached condition (bf16 only): KV = per-head tile stream over the rows b*Nk + l, see vt_attn_kvt.hip
 struct VtAttnKvtParams {
   const void* Q; const void* KV; void* O;
   long q_bs, q_rs;            // Q element strides: batch, row (head h at +h*64)
   long o_bs, o_rs;
   const uint8_t* kmask;       // [B][Nk] or null
-  int B, H, Nq, Nk, T;        // T = tiles of 64 keys per (b, h)
+  int B, H, Nq, Nk, T;        // Nk keys per sample; T = ceil(B*Nk / 64) tiles per head
   float scale;
 };
 // position of key kk (0..63) inside a Vt tile row: within each 32-key half the keys are stored in the k order of the
@@ -43,8 +43,8 @@ struct VtAttnKvtParams {
 // and aligned groups of 4 keys stay contiguous.
 __host__ __device__ inline int vt_kpos(int kk) { return (kk & 32) | (((kk >> 2) & 3) << 3) | (((kk >> 4) & 1) << 2) | (kk & 3); }
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s);
-// row-major K / V projections [B][L][ld] -> the tile stream (either source may be null)
-int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int B, int L, int T, int H, hipStream_t s);
+// row-major K / V projections [M][ld] -> the tile stream (either source may be null)
+int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int M, int T, int H, hipStream_t s);
 
 int vt_gemm_launch(const VtGemmParams& p, hipStream_t s);
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s);

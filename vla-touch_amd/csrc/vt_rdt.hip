@@ -112,9 +112,9 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.emb_tmp = take((size_t)B * D * a); w.sin = take((size_t)B * 256 * a);
   const int n_lang_blk = (d.depth + 1) / 2, n_img_blk = d.depth / 2;
   // per block: fp32 mode [B*L][2D] (K | V interleaved per token); bf16 mode K [B*L][D] followed by Vt [B][H][64][Lpad]
-  // bf16: per-(b, h) tile stream of 16-KiB [K | Vt] tiles (vt_attn_kvt.hip); fp32: row-major [B*L][2D]
-  w.kv_lang_blk = ((size_t)B * D * 2 * lpad64(L) * a + 255) / 256 * 256;
-  w.kv_img_blk = ((size_t)B * D * 2 * lpad64(Li) * a + 255) / 256 * 256;
+  // bf16: per-head tile stream of 16-KiB [K | Vt] tiles over the B*L rows (vt_attn_kvt.hip); fp32: row-major [B*L][2D]
+  w.kv_lang_blk = ((size_t)D * 2 * lpad64(B * L) * a + 255) / 256 * 256;
+  w.kv_img_blk = ((size_t)D * 2 * lpad64(B * Li) * a + 255) / 256 * 256;
   w.kv_lang = take(w.kv_lang_blk * n_lang_blk);
   w.kv_img = take(w.kv_img_blk * n_img_blk);
   const size_t M = (size_t)B * N;
@@ -195,11 +195,11 @@ int cache_cond(RCtx& c) {
     if (d.adt == VT_BF16) {
       // bf16: K (k_norm fused) and V go straight from the GEMM epilogues into the tile stream when the projection takes the
       // large-GEMM path; small shapes go row-major through tmpA / tmpB and the retile kernels.
-      const int T = lpad64(Lc) / 64;
+      const int T = lpad64(c.B * Lc) / 64;
       VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
       VtGemmParams pv = lin(src, d.adt, D, (const char*)b.ckv_w + (size_t)D * D * c.a, d.cdt, D, b.ckv_b + D, kv, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
       pk.cmap = 1; pv.cmap = 2;
-      pk.cmap_L = pv.cmap_L = Lc; pk.cmap_T = pv.cmap_T = T; pk.cmap_H = pv.cmap_H = d.heads;
+      pk.cmap_T = pv.cmap_T = T;
       if (fuse_headnorm(pk, b.ckn, D, nullptr, D, d.rms_mode) && vt_gemm_fast_eligible(pv)) {
         CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
         CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));
@@ -209,7 +209,7 @@ int cache_cond(RCtx& c) {
         CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
         CK(vt_k_headnorm(c.ws + c.w.tmpA, d.adt, D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
         CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));
-        CK(vt_wrap(vt_k_retile_kv(c.ws + c.w.tmpA, c.ws + c.w.tmpB, D, kv, c.B, Lc, T, d.heads, c.s), "rdt cond retile"));
+        CK(vt_wrap(vt_k_retile_kv(c.ws + c.w.tmpA, c.ws + c.w.tmpB, D, kv, c.B * Lc, T, d.heads, c.s), "rdt cond retile"));
       }
     } else {
       VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
@@ -233,7 +233,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
     p.Q = c.ws + c.w.q; p.KV = kv; p.O = c.ws + c.w.att;
     p.q_bs = (long)N * D; p.q_rs = D; p.o_bs = (long)N * D; p.o_rs = D;
     p.kmask = lang ? lang_mask : nullptr;
-    p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(Lc) / 64; p.scale = 0.125f;
+    p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(c.B * Lc) / 64; p.scale = 0.125f;
     return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
   }
   return attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att);

@@ -40,7 +40,7 @@ class GemmParams(C.Structure):
         ("a_dtype", C.c_int), ("w_dtype", C.c_int), ("c_dtype", C.c_int),
         ("hn_w0", C.c_void_p), ("hn_w1", C.c_void_p), ("hn_c0_end", C.c_int), ("hn_c1_end", C.c_int),
         ("hn_eps", C.c_float), ("hn_mode", C.c_int),
-        ("cmap", C.c_int), ("cmap_L", C.c_int), ("cmap_T", C.c_int), ("cmap_H", C.c_int),
+        ("cmap", C.c_int), ("cmap_T", C.c_int),
     ]
 
 

@@ -20,7 +20,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          headnorm=None, cmap=None) -> torch.Tensor:
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
-    cmap = (mode, L, T, H) with out= a [B, H, T, 2, 64, 64] tile stream: the cached-condition K (mode 1) / Vt (mode 2) layout."""
+    cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
@@ -45,7 +45,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         p.hn_w1, p.hn_c1_end = (0 if w1 is None else w1.data_ptr()), c1
         p.hn_eps, p.hn_mode = eps, mode
     if cmap is not None:
-        p.cmap, p.cmap_L, p.cmap_T, p.cmap_H = cmap
+        p.cmap, p.cmap_T = cmap
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
     return out
 
