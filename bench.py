@@ -245,6 +245,14 @@ def main():
                        "not in the reference)", "setup_s": round(setup_s, 1),
         },
     }
+    # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/pmc_summary.py); the committed summary of
+    # the last such run is attached when present (null otherwise: counters cannot be read from inside this process)
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+    except Exception:
+        pass
+
     def roof(mode, name):
         ms_, fl_, by_, n_ = prof[mode]
         if n_ <= 0 or ms_ <= 0:
@@ -253,7 +261,10 @@ def main():
         return {"kernel": name, "bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2),
                 "algorithmic_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
-                "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3), "traffic": None}
+                "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3),
+                "traffic": (round(pmc[name.split(" ")[0]]["per_launch_bytes"] / 1e9, 4) if name.split(" ")[0] in pmc else None),
+                "traffic_unit": "GB per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
+                "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4)}
     r_pp = roof(2, "gemm_pp256_kernel (256x256x64 ping-pong tile, 16-bit MFMA: condition K/V projections, image adaptor, DINOv2 Linears)")
     r_gl = roof(3, "gemm_glds_kernel (64/128 x 128 x 64 LDS-DMA tiles, 16-bit MFMA: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
     if r_pp is not None:

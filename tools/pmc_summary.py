@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM traffic of the dominant kernel class from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch).
 gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE counts 128-B requests at 64 B -> doubled for wide coalesced reads.
-    python tools/pmc_summary.py gpurun_out/pmc/pmc_FETCH_SIZE_counter_collection.csv gpurun_out/pmc/pmc_WRITE_SIZE_counter_collection.csv"""
+    python tools/pmc_summary.py gpurun_out/pmc/pmc_FETCH_SIZE_counter_collection.csv gpurun_out/pmc/pmc_WRITE_SIZE_counter_collection.csv [profiles/pmc_traffic.json]"""
 import csv, sys, re
 from collections import defaultdict
 
@@ -26,6 +26,12 @@ for k in fetch:
     rows.append((2 * f * 1024 + w * 1024, k, n, 2 * f * 1024, w * 1024))
 for tot, k, n, rd, wr in sorted(rows, reverse=True)[:12]:
     print(f"{k[:70]:70s} n={n:5d} read={rd/1e9:8.2f} GB write={wr/1e9:8.2f} GB  per-dispatch={(rd+wr)/n/1e6:9.2f} MB")
-g = [r for r in rows if "gemm_glds_kernel" in r[1]]
-tot = sum(r[0] for r in g); n = sum(r[2] for r in g)
-print(f"GEMM_GLDS_TOTAL dispatches={n} bytes={tot:.0f} per_launch_bytes={tot/max(n,1):.0f}")
+import json
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes), bench.py --steps 1 --warmup 1 --no-graph; bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}
+for cls in ("gemm_pp256_kernel", "gemm_glds_kernel", "attn_kvt_kernel"):
+    g = [r for r in rows if cls in r[1]]
+    tot = sum(r[0] for r in g); n = sum(r[2] for r in g)
+    print(f"CLASS {cls}: dispatches={n} bytes={tot:.0f} per_launch_bytes={tot/max(n,1):.0f}")
+    out[cls] = {"dispatches": n, "per_launch_bytes": tot / max(n, 1)}
+if len(sys.argv) > 3:
+    json.dump(out, open(sys.argv[3], "w"), indent=1)
