@@ -38,7 +38,9 @@ def test_mfma_fragment_layouts(dev):
 ACTS = {0: lambda x: x, 1: lambda x: F.gelu(x), 2: lambda x: F.gelu(x, approximate="tanh"), 3: F.silu, 4: F.mish}
 
 
-@pytest.mark.parametrize("M,N,K", [(32, 256, 784), (70, 100, 40), (512, 512, 1280), (1000, 768, 592), (4112, 2304, 768), (33, 10, 256)])
+# (2144, 2048, 1088): one round of 160x128 tiles -> the in-block split-K ping-pong kernel, odd number of k-tiles (17)
+@pytest.mark.parametrize("M,N,K", [(32, 256, 784), (70, 100, 40), (512, 512, 1280), (1000, 768, 592), (4112, 2304, 768), (33, 10, 256), (2144, 2048, 1088),
+                                   (2100, 1920, 1024)])
 @pytest.mark.parametrize("mode", ["f32", "bf16", "a32w16", "f16"])
 def test_gemm_plain(dev, M, N, K, mode):
     from vlatouch import ops
@@ -181,7 +183,7 @@ def test_action_normalize_matches_golden(dev):
         assert np.abs(out.cpu().numpy() - g["d_" + key[2:]]).max() < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(2144, 6144, 2048), (4374, 4096, 2048), (1000, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(2144, 6144, 2048), (4374, 4096, 2048), (1000, 768, 3072), (2144, 2048, 2048), (35000, 2048, 512)])
 def test_gemm_large_path_with_fused_headnorm(dev, M, N, K):
     """The LDS-DMA large-GEMM kernel incl. its fused per-head RMSNorm epilogue (q_norm | k_norm | v untouched)."""
     from vlatouch import ops, _lib as L
@@ -207,3 +209,30 @@ def test_gemm_large_path_with_fused_headnorm(dev, M, N, K):
         assert rel_err(out, ref.reshape(M, N)) < 3e-3, mode
         outb = ops.gemm(a, w, bias, out_dtype=torch.bfloat16, headnorm=(w0, c0, w1, c1, 1e-6, mode))
         assert rel_err(outb.float(), ref.reshape(M, N)) < 1e-2
+
+
+@pytest.mark.parametrize("M,K", [(900, 256), (70001, 512)])          # 128-column kernel / 256-square ping-pong kernel
+def test_gemm_condition_tile_stream_outputs(dev, M, K):
+    """cmap 1 / 2: the K / Vt halves of the cached-condition tile stream written from the GEMM epilogue == the row-major GEMM
+    re-laid out on the host (tile(h, t) = [K: 64 rows x 64 d][Vt: 64 d x 64 rows in MFMA k order])."""
+    from vlatouch import ops
+    N, H = 2048, 32
+    T = (M + 63) // 64
+    a = rnd((M, K), 1, dev, torch.bfloat16)
+    w = rnd((N, K), 2, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    ref = ops.gemm(a, w, bias, out_dtype=torch.bfloat16)                       # [M, N] bf16, same kernels, plain layout
+    pad = torch.zeros(T * 64, N, dtype=torch.bfloat16, device=dev)
+    pad[:M] = ref
+    rows = pad.reshape(T, 64, H, 64)                                           # [t, r, h, d]
+    kk = torch.arange(64)
+    pos = (kk & 32) | (((kk >> 2) & 3) << 3) | (((kk >> 4) & 1) << 2) | (kk & 3)   # vt_kpos
+    kv = torch.full((H, T, 2, 64, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    ops.gemm(a, w, bias, out=kv, out_dtype=torch.bfloat16, cmap=(1, T))
+    ops.gemm(a, w, bias, out=kv, out_dtype=torch.bfloat16, cmap=(2, T))
+    valid = (torch.arange(T * 64, device=dev) < M).reshape(T, 64)
+    got_k = kv[:, :, 0].permute(1, 2, 0, 3)                                    # [t, r, h, d]
+    assert torch.equal(got_k[valid], rows[valid])
+    got_v = torch.empty(T, 64, H, 64, dtype=torch.bfloat16, device=dev)        # undo the k order: row kk sits at pos[kk]
+    got_v[:, kk] = kv[:, :, 1][:, :, :, pos.to(dev)].permute(1, 3, 0, 2)       # [h,t,d,kk] -> [t,kk,h,d]
+    assert torch.equal(got_v[valid], rows[valid])

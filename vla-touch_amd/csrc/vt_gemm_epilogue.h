@@ -80,11 +80,14 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
   const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
 #pragma unroll
   for (int jp = 0; jp < TM; jp += 2) {
+    constexpr int NROWS_FULL = 32;
+    const int nrows = (TM - jp >= 2) ? NROWS_FULL : 16;        // odd TM: the last patch holds one 16-row tile
 #pragma unroll
     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float4_t a = acc[i][jp + jj];
+        if (jp + jj >= TM) continue;
+        const float4_t a = acc[i][jp + jj < TM ? jp + jj : TM - 1];
         if constexpr (CMAP == 2) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) ep[(i * 16 + g * 4 + r) * EPT_LD + jj * 16 + l15] = a[r];
@@ -102,7 +105,7 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
         const float4 x = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + kq);
         const float bv = bias ? bias[ncol0 + dd] : 0.f;
         const int m = mrow0 + jp * 16 + kq;
-        if (m < p.M) {
+        if (m < p.M && kq < nrows) {
           TC* dst = Cg + ((tbase + (m >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(m & 63);
           TC ov[4] = {Elem<TC>::from_f(x.x + bv), Elem<TC>::from_f(x.y + bv), Elem<TC>::from_f(x.z + bv), Elem<TC>::from_f(x.w + bv)};
           if (m + 3 < p.M) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(ov);
@@ -114,7 +117,7 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
       // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
       if (p.act != VT_ACT_NONE) {
 #pragma unroll 1
-        for (int it = 0; it < 8; ++it) {
+        for (int it = 0; it < nrows / 4; ++it) {
           const int row = it * 4 + (lane >> 4);
           const float4 x = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);
           vt_epi_segment<TC, CMAP, true>(p, x, b4, cs4, hw, hw4, Cg, Rg, mrow0 + jp * 16 + row, n, ncol0, col_ok);
@@ -122,6 +125,7 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
       } else {
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
+          if (it * 4 >= nrows) break;
           const int row = it * 4 + (lane >> 4);
           const float4 x = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);
           vt_epi_segment<TC, CMAP, false>(p, x, b4, cs4, hw, hw4, Cg, Rg, mrow0 + jp * 16 + row, n, ncol0, col_ok);

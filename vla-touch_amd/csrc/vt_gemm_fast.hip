@@ -167,6 +167,7 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   // 128-row tiles when they fill the slots, else 64-row tiles.  GEMMs with several rounds of 256-square tiles go to the
   // ping-pong kernel of vt_gemm_pp.hip (half the L2 -> LDS bytes per flop).
   if (g_vt_force_bm == 256 || (g_vt_force_bm == 0 && vt_gemm_pp_eligible(p))) return vt_gemm_pp_launch(p, s);
+  if ((g_vt_force_bm == 160 || g_vt_force_bm == 0) && vt_gemm_ppk_eligible(p)) return vt_gemm_ppk_launch(p, s);
   int bm = tiles128 < 1024 ? 64 : 128;
   if (g_vt_force_bm == 64 || g_vt_force_bm == 128) bm = g_vt_force_bm;
   const int bn = 128;

@@ -33,4 +33,6 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p);
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p);
 bool vt_gemm_pp_eligible(const VtGemmParams& p);          // vt_gemm_pp.hip: 256-square ping-pong tile
 int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s);
+bool vt_gemm_ppk_eligible(const VtGemmParams& p);         // vt_gemm_ppk.hip: 160 x 128 tile, in-block split-K ping-pong, one round
+int vt_gemm_ppk_launch(const VtGemmParams& p, hipStream_t s);
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s);
