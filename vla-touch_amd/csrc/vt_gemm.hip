@@ -58,6 +58,21 @@ __device__ __forceinline__ void split8(const float* p, uint4& hi, uint4& lo) {
   lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
+// the same split on 8 floats already in registers (two raw 16-B loads): hi = bf16(x), lo = bf16(x - hi), packed pairwise
+__device__ __forceinline__ void split8r(const uint4& a, const uint4& b, uint4& hi, uint4& lo) {
+  const float f[8] = {__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z), __uint_as_float(a.w),
+                      __uint_as_float(b.x), __uint_as_float(b.y), __uint_as_float(b.z), __uint_as_float(b.w)};
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = pk_bf16(f[2 * j], f[2 * j + 1]);
+    const float r0 = f[2 * j] - __uint_as_float(h[j] << 16), r1 = f[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u);
+    l[j] = pk_bf16(r0, r1);
+  }
+  hi = make_uint4(h[0], h[1], h[2], h[3]);
+  lo = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
 template <typename TC> struct Store4;
 template <> struct Store4<float> {
   __device__ static __forceinline__ void st(float* p, const float v[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
@@ -167,8 +182,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
         }
       }
       if (src) {
-        if constexpr (X3) split8(src, v, v2);
-        else v = ChunkLoad<TA, TCmp>::load(src);
+        if constexpr (X3) {      // raw fp32 now, hi/lo split in store_tile: splitting here would wait for the load before the MFMAs
+          v = *reinterpret_cast<const uint4*>(src);
+          v2 = *reinterpret_cast<const uint4*>(src + 4);
+        } else v = ChunkLoad<TA, TCmp>::load(src);
       }
       ra[i] = v;
       if constexpr (X3) ra2[i] = v2;
@@ -177,8 +194,10 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
     for (int i = 0; i < PB; ++i) {
       uint4 v = make_uint4(0, 0, 0, 0), v2 = make_uint4(0, 0, 0, 0);
       if (w_ok[i] && kin) {
-        if constexpr (X3) split8(W + w_row_off[i] + k, v, v2);
-        else v = *reinterpret_cast<const uint4*>(W + w_row_off[i] + k);
+        if constexpr (X3) {
+          v = *reinterpret_cast<const uint4*>(W + w_row_off[i] + k);
+          v2 = *reinterpret_cast<const uint4*>(W + w_row_off[i] + k + 4);
+        } else v = *reinterpret_cast<const uint4*>(W + w_row_off[i] + k);
       }
       rb[i] = v;
       if constexpr (X3) rb2[i] = v2;
@@ -188,14 +207,26 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
       const int r = i * 32 + cr;
-      *reinterpret_cast<uint4*>(As + r * 128 + swz(r, cc) * 16) = ra[i];
-      if constexpr (X3) *reinterpret_cast<uint4*>(As2 + r * 128 + swz(r, cc) * 16) = ra2[i];
+      if constexpr (X3) {
+        uint4 hi, lo;
+        split8r(ra[i], ra2[i], hi, lo);
+        *reinterpret_cast<uint4*>(As + r * 128 + swz(r, cc) * 16) = hi;
+        *reinterpret_cast<uint4*>(As2 + r * 128 + swz(r, cc) * 16) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(As + r * 128 + swz(r, cc) * 16) = ra[i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
       const int r = i * 32 + cr;
-      *reinterpret_cast<uint4*>(Bs + r * 128 + swz(r, cc) * 16) = rb[i];
-      if constexpr (X3) *reinterpret_cast<uint4*>(Bs2 + r * 128 + swz(r, cc) * 16) = rb2[i];
+      if constexpr (X3) {
+        uint4 hi, lo;
+        split8r(rb[i], rb2[i], hi, lo);
+        *reinterpret_cast<uint4*>(Bs + r * 128 + swz(r, cc) * 16) = hi;
+        *reinterpret_cast<uint4*>(Bs2 + r * 128 + swz(r, cc) * 16) = lo;
+      } else {
+        *reinterpret_cast<uint4*>(Bs + r * 128 + swz(r, cc) * 16) = rb[i];
+      }
     }
   };
 
