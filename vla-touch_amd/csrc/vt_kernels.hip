@@ -154,16 +154,18 @@ __global__ __launch_bounds__(256) void headnorm_kernel(T* __restrict__ x, long t
 }
 
 // ------------------------------------------------------------------ GroupNorm + Mish (+FiLM) (+residual) over partial slabs
+// One 256-thread block per (net, sample, group): the unit has only C/8 * T = 256..1024 values but each is the sum of up to 8
+// split-K slabs, so the kernel is a latency chain of small loads; a block per unit (instead of a wave) quarters the chain and
+// the slab loads of a value are issued together (unrolled, predicated) rather than one dependent add at a time.
+constexpr int GN_MAX_SLABS = 8;
 template <typename TO>
 __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int unit = blockIdx.x * 4 + wv;
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int unit = blockIdx.x;
   const int cpg = p.C / p.ngroups;
   const int n = cpg * p.T;
-  float* sm = gsm + (size_t)wv * n;
-  const int total = p.nets * p.B * p.ngroups;
-  if (unit >= total) return;
   const int net = unit / (p.B * p.ngroups);
   const int rem = unit - net * p.B * p.ngroups;
   const int b = rem / p.ngroups, grp = rem - b * p.ngroups;
@@ -172,25 +174,37 @@ __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
   const float* gamma = p.gamma + (long)net * p.vec_gs;
   const float* beta = p.beta + (long)net * p.vec_gs;
   const int c0 = grp * cpg;
+  auto block_sum = [&](float t) {
+    t = wave_sum(t);
+    __syncthreads();
+    if (lane == 0) red[wv] = t;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
   float s = 0.f;
-  for (int e = lane; e < n; e += 64) {
+  for (int e = tid; e < n; e += 256) {
     const int t = e / cpg, c = e - t * cpg;
     const long off = ((long)b * p.T + t) * p.ldp + c0 + c;
+    float part[GN_MAX_SLABS];
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLABS; ++k) part[k] = k < p.nslabs ? P[(long)k * p.slab_stride + off] : 0.f;
     float v = bias ? bias[c0 + c] : 0.f;
-    for (int k = 0; k < p.nslabs; ++k) v += P[(long)k * p.slab_stride + off];
-    sm[e] = v;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLABS; ++k) v += part[k];          // same order as a sequential sum over the slabs
+    for (int k = GN_MAX_SLABS; k < p.nslabs; ++k) v += P[(long)k * p.slab_stride + off];
+    gsm[e] = v;
     s += v;
   }
-  const float mean = wave_sum(s) / (float)n;
+  const float mean = block_sum(s) / (float)n;
   float q = 0.f;
-  for (int e = lane; e < n; e += 64) { const float d = sm[e] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) / (float)n + p.eps);
+  for (int e = tid; e < n; e += 256) { const float d = gsm[e] - mean; q += d * d; }
+  const float rstd = rsqrtf(block_sum(q) / (float)n + p.eps);
   const float* film = p.film ? p.film + (long)net * p.film_gs + (long)b * p.film_ld + p.film_off : nullptr;
   const TO* R = p.residual ? reinterpret_cast<const TO*>(p.residual) + (long)net * p.r_gs : nullptr;
   TO* O = reinterpret_cast<TO*>(p.out) + (long)net * p.o_gs;
-  for (int e = lane; e < n; e += 64) {
+  for (int e = tid; e < n; e += 256) {
     const int t = e / cpg, c = e - t * cpg, col = c0 + c;
-    float y = (sm[e] - mean) * rstd * gamma[col] + beta[col];
+    float y = (gsm[e] - mean) * rstd * gamma[col] + beta[col];
     y = act_apply(y, VT_ACT_MISH);
     if (film) y = film[col] * y + film[p.C + col];
     const long row = (long)b * p.T + t;
@@ -408,10 +422,10 @@ int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, cons
 int vt_k_groupnorm(const VtGnParams& p, hipStream_t s) {
   if (p.C % p.ngroups) return VT_ERR_ARG;
   const int n = (p.C / p.ngroups) * p.T;
-  const size_t smem = (size_t)4 * n * sizeof(float);
+  const size_t smem = (size_t)n * sizeof(float);
   if (smem > 64 * 1024) return VT_ERR_UNSUPPORTED;
   const int units = p.nets * p.B * p.ngroups;
-  DISPATCH_T(p.out_dtype, TO, hipLaunchKernelGGL((gn_kernel<TO>), dim3((units + 3) / 4), dim3(256), smem, s, p))
+  DISPATCH_T(p.out_dtype, TO, hipLaunchKernelGGL((gn_kernel<TO>), dim3(units), dim3(256), smem, s, p))
   return vt_check_launch();
 }
 
