@@ -398,7 +398,7 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
                  float eps, int mode, hipStream_t s) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
-  if (xdt == VT_F32 && D >= 1024 && rows >= 256 && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row
+  if (xdt == VT_F32 && D >= 512 && rows >= 256 && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row
     if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
     else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode);
     else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode);
