@@ -266,7 +266,7 @@ def main():
                 "traffic_unit": "GB per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
                 "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4)}
     r_pp = roof(2, "gemm_pp256_kernel (256x256x64 ping-pong tile, 16-bit MFMA: condition K/V projections, image adaptor, DINOv2 Linears)")
-    r_gl = roof(3, "gemm_glds_kernel (64/128 x 128 x 64 LDS-DMA tiles, 16-bit MFMA: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
+    r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
     if r_pp is not None:
         res["roofline"] = r_pp
         if r_gl is not None:
