@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dino", default="base", choices=["small", "base"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt"],
+    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip"],
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
@@ -134,9 +134,22 @@ def main():
         amask[:, :, :10] = 1.0                                       # the 10 EEF dims of the unified action vector
         rin = dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
                    state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
+    sig = sig_px = None
+    if args.workload == "siglip":       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
+        from vlatouch import synth
+        from vlatouch.engine import SiglipEngine
+        c = synth.SIGLIP_CONFIGS["so400m"]
+        wdt = torch.float32
+        ssd = synth.fill_state_dict_device(synth.siglip_shapes(**c), dev, wdt, seed=9)
+        sig = SiglipEngine({k: v.cpu() for k, v in ssd.items()}, heads=c["heads"], precision="fp16" if args.precision == "bf16" else "fp32", device=dev)
+        del ssd
+        sig_px = (2.0 * torch.rand(6 * B, 3, 384, 384, device=dev) - 1.0)
     setup_s = time.time() - t0
 
     def step():
+        if args.workload == "siglip":
+            out_holder["out"] = sig.forward(sig_px)
+            return
         if args.workload == "dino_mlp":
             out_holder["out"] = ctrl.encode_observation(inp["state"], inp["cam1"], inp["cam2"], inp["forces"])
             return
@@ -228,6 +241,8 @@ def main():
                       "pi_refine: 2x DINOv2-%s CLS @%d + state/force MLP + 10-step interpolant SDE (v_net+s_net), T=%d; BASELINE configs[3] "
                       "WITHOUT the RDT-1B chunk generator" % (args.dino, args.res, T)),
         "dino_mlp": ("encoded observations/sec", "dino_mlp = BASELINE configs[1]: 2x DINOv2-%s @%d + state/force MLP" % (args.dino, args.res)),
+        "siglip": ("chunks' worth of image tokens/sec (6 frames per chunk)", "siglip (SURVEY 8f-1): SigLIP-so400m-patch14-384 tower, 6 x 384x384 frames per "
+                   "chunk -> 6 x 729 x 1152 image tokens, batch %d chunks (%d images per step)" % (B, 6 * B)),
         "rdt": ("RDT-1B action chunks/sec", "rdt = BASELINE configs[2] shape: RDT-1B, %d-step DPM-Solver++, cached T5-sized (4096-d) language "
                 "tokens, batch %d" % (args.rdt_steps, B)),
     }[args.workload]

@@ -109,6 +109,14 @@ typedef struct {
   int hidden, layers, heads, patch, kpad;   /* kpad = 3*patch*patch rounded up to 16 (592) */
   int cdt, adt;
   float eps;
+  /* ViT variants beyond DINOv2 (all 0 = DINOv2): SigLIP has no CLS token, tanh-GELU, 72-wide heads packed zero-padded to 96,
+   * an FFN width that is not 4*hidden, and returns every token after the final LayerNorm */
+  int no_cls;        /* 1: no CLS token (tokens = patches) */
+  int act;           /* 0: erf GELU (VT_ACT_GELU_ERF); else a VT_ACT_* code */
+  int head_dim;      /* 0 / 64, or 96 (attention width heads*head_dim; weights packed accordingly) */
+  int mlp_dim;       /* 0: 4*hidden; else the (64-padded) FFN width */
+  int out_all;       /* 0: out = [ncams][B][hidden] CLS rows; 1: out = [ncams][B][tokens][hidden] */
+  float attn_scale;  /* 0: head_dim^-0.5 */
 } vt_dino_desc;
 int vt_dino_create(const vt_dino_desc* desc, const void* const* weights, int n_weights, vt_dino_t* out);
 void vt_dino_destroy(vt_dino_t h);

@@ -41,6 +41,16 @@ def dino_sd(size: str = "small") -> Dict[str, torch.Tensor]:
     return sd_torch(synth.dinov2_shapes(c["hidden"], c["layers"]), prefix=f"dinov2-{size}.")
 
 
+def siglip_sd(name: str = "tiny") -> Dict[str, torch.Tensor]:
+    return sd_torch(synth.siglip_shapes(**synth.SIGLIP_CONFIGS[name]), prefix=f"siglip-{name}.")
+
+
+def siglip_pixels(B: int, res: int, seed: int = 8) -> torch.Tensor:
+    """SiglipImageProcessor output range: (x/255 - 0.5) / 0.5 in [-1, 1]."""
+    g = synth.inputs_rng(seed)
+    return T((2.0 * g.random((B, 3, res, res), dtype=np.float32) - 1.0))
+
+
 def state_encoder_sd(obs_dim: int) -> Dict[str, torch.Tensor]:
     return sd_torch(synth.state_encoder_shapes(obs_dim), prefix="state_encoder.")
 

@@ -236,3 +236,20 @@ def test_gemm_condition_tile_stream_outputs(dev, M, K):
     got_v = torch.empty(T, 64, H, 64, dtype=torch.bfloat16, device=dev)        # undo the k order: row kk sits at pos[kk]
     got_v[:, kk] = kv[:, :, 1][:, :, :, pos.to(dev)].permute(1, 3, 0, 2)       # [h,t,d,kk] -> [t,kk,h,d]
     assert torch.equal(got_v[valid], rows[valid])
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16", "f16"])
+@pytest.mark.parametrize("Nq,Nk", [(729, 729), (36, 36), (100, 257)])
+def test_attention_head_dim_96(dev, mode, Nq, Nk):
+    """hd = 96 (SigLIP's 72-wide heads zero-padded): scale passed explicitly as 72 ** -0.5."""
+    from vlatouch import ops
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[mode]
+    B, H = 2, 3
+    qkv = rnd((B, max(Nq, Nk), 3, H, 96), 1, dev, dt)
+    qkv[..., 72:] = 0
+    q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
+    out = ops.attention(q, k, v, scale=72 ** -0.5)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * 72 ** -0.5
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, Nq, H * 96)
+    assert rel_err(out.float(), ref) < {"f32": 3e-5, "bf16": 1.5e-2, "f16": 2e-3}[mode]
+    assert float(out.float().reshape(B, Nq, H, 96)[..., 72:].abs().max()) == 0.0

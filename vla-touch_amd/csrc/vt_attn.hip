@@ -75,13 +75,14 @@ template <> struct VtRead<float> {
 // blockDim.x = 64 * NW (NW = 4..8 waves); a block owns 16*NW query rows of one (batch, head); NW is chosen by the host
 // to minimise padded query rows (e.g. 5 waves = 80 rows for RDT's 67 queries, so its 4 374-key cross-attention streams
 // K/V once per (batch, head) instead of twice).
-template <typename T>
+// HD = head dimension, 64 or 96 (SigLIP's 72-wide heads run zero-padded to 96: its QKV / projection weights are packed that way).
+template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
-  constexpr int HD = 64, KT = 64;
+  constexpr int KT = 64;
   constexpr int ES = sizeof(T);
   constexpr int EPC = Elem<T>::EPC;
   constexpr int EPR = 128 / ES;            // elements per 128-B LDS row (64 bf16 / 32 f32)
-  constexpr int SUB = HD / EPR;            // 128-B sub-tiles per key row (1 / 2)
+  constexpr int SUB = (HD + EPR - 1) / EPR; // 128-B sub-tiles per key row
   constexpr int CPK = HD / EPC;            // 16-B chunks per key row (8 / 16)
   constexpr int VSTR = 68 * ES;            // Vt row stride in bytes (64 keys + 4 pad)
   __shared__ __attribute__((aligned(16))) char smem[SUB * KT * 128 + HD * VSTR];
@@ -98,13 +99,14 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
   const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.km_bs : nullptr;
 
-  Frag<T> qf[2];
+  constexpr int NKS = HD / 32, NDT = HD / 16;      // 32-deep k-steps of Q.K, 16-row tiles of the output's d dimension
+  Frag<T> qf[NKS];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+  for (int ks = 0; ks < NKS; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
 
-  float4_t o[4];
+  float4_t o[NDT];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NDT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const float cscale = p.scale * 1.4426950408889634f;
 
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
     for (int kt = 0; kt < 4; ++kt) {
       sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < NKS; ++ks) {
         const int d0 = ks * 32 + g * 8;
         Frag<T> kf;
         lds_frag(kf, Ks + (d0 / EPR) * (KT * 128), kt * 16 + l15, (d0 % EPR) / 8);
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
       const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
       l_run *= alpha;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
       m_run = m_new;
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
       Frag<T> pf;
       PackP<T>::pack(pf, pj);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
+      for (int dt = 0; dt < NDT; ++dt) {
         Frag<T> vf;
         const char* row = Vt + (dt * 16 + l15) * VSTR;
         VtRead<T>::rd(vf, 0, row + (kb * 32 + g * 4) * ES);
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
   if (q < p.Nq) {
     T* O = reinterpret_cast<T*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
+    for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) O[dt * 16 + g * 4 + r] = Elem<T>::from_f(o[dt][r] * inv);
   }
@@ -226,8 +228,15 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   }
   const int rows = nw * 16;
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
-  if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t>), grid, dim3(64 * nw), 0, s, p);
-  else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t>), grid, dim3(64 * nw), 0, s, p);
-  else hipLaunchKernelGGL((attn_kernel<float>), grid, dim3(64 * nw), 0, s, p);
+  if (p.hd != 0 && p.hd != 64 && p.hd != 96) return VT_ERR_UNSUPPORTED;
+  if (p.hd == 96) {
+    if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 96>), grid, dim3(64 * nw), 0, s, p);
+    else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t, 96>), grid, dim3(64 * nw), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<float, 96>), grid, dim3(64 * nw), 0, s, p);
+  } else {
+    if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 64>), grid, dim3(64 * nw), 0, s, p);
+    else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t, 64>), grid, dim3(64 * nw), 0, s, p);
+    else hipLaunchKernelGGL((attn_kernel<float, 64>), grid, dim3(64 * nw), 0, s, p);
+  }
   return vt_check_launch();
 }

@@ -22,11 +22,12 @@ struct VtAttnParams {
   long q_bs, q_rs, q_hs;      // element strides: batch, row(token), head
   long k_bs, k_rs, k_hs;
   long v_bs, v_rs, v_hs;
-  long o_bs, o_rs;            // output [B, Nq, H*64]
+  long o_bs, o_rs;            // output [B, Nq, H*hd]
   const uint8_t* kmask; long km_bs;   // optional key mask [B, Nk] (1 = attend)
   int B, H, Nq, Nk;
   float scale;
   int dtype;
+  int hd;                     // head dimension: 0 or 64 -> 64; 96
 };
 
 // cross-attention against the cached condition (bf16 only): KV = per-head tile stream over the rows b*Nk + l, see vt_attn_kvt.hip

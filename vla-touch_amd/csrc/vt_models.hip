@@ -47,8 +47,10 @@ int vt_dino_num_weights(const vt_dino_desc* d) { return 3 + 14 * d->layers + 2; 
 int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_dino_t* out) {
   if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_dino_create: null argument");
   const vt_dino_desc& d = *desc;
-  if (d.layers < 1 || d.layers > 48 || d.hidden % 64 || d.hidden / d.heads != 64 || d.patch != 14 || d.kpad % 16 || d.kpad < 588)
-    return vt_fail(VT_ERR_ARG, "vt_dino_create: unsupported config (head_dim must be 64, patch 14)");
+  const int hd = d.head_dim ? d.head_dim : 64;
+  if (d.layers < 1 || d.layers > 48 || d.hidden % 64 || (hd != 64 && hd != 96) || (hd == 64 && d.hidden / d.heads != 64) || d.patch != 14 ||
+      d.kpad % 16 || d.kpad < 588 || (d.mlp_dim % 16))
+    return vt_fail(VT_ERR_ARG, "vt_dino_create: unsupported config (head_dim 64 / 96, patch 14)");
   if (n != vt_dino_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_dino_create: expected %d weights, got %d", vt_dino_num_weights(desc), n);
   for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_dino_create: weight %d is null", k);
   vt_dino_s* h = new (std::nothrow) vt_dino_s();
@@ -73,16 +75,17 @@ namespace {
 struct DWs { size_t part, flags, apatch, tok, xn, qkv, att, h1, total; };
 DWs dcarve(const vt_dino_s* h, int Bt, int res) {
   const vt_dino_desc& d = h->d;
-  const int a = es(d.adt), g = res / d.patch, N = g * g + 1, D = d.hidden;
+  const int a = es(d.adt), g = res / d.patch, N = g * g + (d.no_cls ? 0 : 1), D = d.hidden;
+  const int Da = d.heads * (d.head_dim ? d.head_dim : 64), Dm = d.mlp_dim ? d.mlp_dim : 4 * D;
   DWs w; size_t o = 0;
   auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
   w.part = take(512 * 4 * 8); w.flags = take(8 * 4 * 8);
   w.apatch = take((size_t)Bt * g * g * d.kpad * a);
   w.tok = take((size_t)Bt * N * D * 4);
   w.xn = take((size_t)Bt * N * D * a);
-  w.qkv = take((size_t)Bt * N * 3 * D * a);
-  w.att = take((size_t)Bt * N * D * a);
-  w.h1 = take((size_t)Bt * N * 4 * D * a);
+  w.qkv = take((size_t)Bt * N * 3 * Da * a);
+  w.att = take((size_t)Bt * N * Da * a);
+  w.h1 = take((size_t)Bt * N * Dm * a);
   w.total = o;
   return w;
 }
@@ -96,7 +99,10 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
   if (ncams < 1 || ncams > 8 || B < 1 || res < 14) return vt_fail(VT_ERR_ARG, "vt_dino_forward: bad sizes");
   const vt_dino_desc& d = h->d;
   hipStream_t s = (hipStream_t)stream;
-  const int g = res / d.patch, np = g * g, N = np + 1, D = d.hidden, Bt = ncams * B, a = es(d.adt);
+  const int g = res / d.patch, np = g * g, cls = d.no_cls ? 0 : 1, N = np + cls, D = d.hidden, Bt = ncams * B, a = es(d.adt);
+  const int hd = d.head_dim ? d.head_dim : 64, Da = d.heads * hd, Dm = d.mlp_dim ? d.mlp_dim : 4 * D;
+  const int act = d.act ? d.act : VT_ACT_GELU_ERF;
+  const float scale = d.attn_scale > 0.f ? d.attn_scale : 1.0f / sqrtf((float)hd);
   char* ws = (char*)workspace;
   const DWs w = dcarve(h, Bt, res);
   float* tok = (float*)(ws + w.tok);
@@ -111,37 +117,38 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
   }
   // 2. patch-embed GEMM, one group per image, + position embedding (shared residual) -> fp32 tokens rows 1..np
   {
-    VtGemmParams p = lin(ws + w.apatch, d.adt, d.kpad, h->patch_w, d.cdt, d.kpad, h->patch_b, tok + D, VT_F32, D, np, D, d.kpad, VT_ACT_NONE);
+    VtGemmParams p = lin(ws + w.apatch, d.adt, d.kpad, h->patch_w, d.cdt, d.kpad, h->patch_b, tok + (size_t)cls * D, VT_F32, D, np, D, d.kpad, VT_ACT_NONE);
     p.groups = Bt; p.a_gs = (long)np * d.kpad; p.w_gs = 0; p.c_gs = (long)N * D; p.bias_gs = 0;
     p.residual = pos_patch; p.ldr = D; p.r_gs = 0;
     CK(vt_wrap(vt_gemm_launch(p, s), "dino patch embed"));
-    CK(vt_k_bcast_row(h->cls_pos0, tok, (long)N * D, Bt, D, s));
+    if (cls) CK(vt_k_bcast_row(h->cls_pos0, tok, (long)N * D, Bt, D, s));
   }
   const int M = Bt * N;
   for (int l = 0; l < d.layers; ++l) {
     const DinoLayer& L = h->L[l];
     CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln1_w, L.ln1_b, M, D, d.eps, VT_NORM_LAYER, s));
-    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, 3 * Da, M, 3 * Da, D, VT_ACT_NONE);
       CK(vt_wrap(vt_gemm_launch(p, s), "dino qkv")); }
     { VtAttnParams p;
       memset(&p, 0, sizeof(p));
-      p.Q = ws + w.qkv; p.K = ws + w.qkv + (size_t)D * a; p.V = ws + w.qkv + (size_t)2 * D * a; p.O = ws + w.att;
-      p.q_bs = p.k_bs = p.v_bs = (long)N * 3 * D; p.q_rs = p.k_rs = p.v_rs = 3 * D; p.q_hs = p.k_hs = p.v_hs = 64;
-      p.o_bs = (long)N * D; p.o_rs = D;
-      p.B = Bt; p.H = d.heads; p.Nq = N; p.Nk = N; p.scale = 0.125f; p.dtype = d.adt;
+      p.Q = ws + w.qkv; p.K = ws + w.qkv + (size_t)Da * a; p.V = ws + w.qkv + (size_t)2 * Da * a; p.O = ws + w.att;
+      p.q_bs = p.k_bs = p.v_bs = (long)N * 3 * Da; p.q_rs = p.k_rs = p.v_rs = 3 * Da; p.q_hs = p.k_hs = p.v_hs = hd;
+      p.o_bs = (long)N * Da; p.o_rs = Da;
+      p.B = Bt; p.H = d.heads; p.Nq = N; p.Nk = N; p.scale = scale; p.dtype = d.adt; p.hd = hd;
       CK(vt_wrap(vt_attn_launch(p, s), "dino attention")); }
-    { VtGemmParams p = lin(ws + w.att, d.adt, D, L.proj_w, d.cdt, D, L.proj_b, tok, VT_F32, D, M, D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(ws + w.att, d.adt, Da, L.proj_w, d.cdt, Da, L.proj_b, tok, VT_F32, D, M, D, Da, VT_ACT_NONE);
       p.colscale = L.ls1; p.residual = tok; p.ldr = D;
       CK(vt_wrap(vt_gemm_launch(p, s), "dino proj")); }
     CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln2_w, L.ln2_b, M, D, d.eps, VT_NORM_LAYER, s));
-    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, 4 * D, M, 4 * D, D, VT_ACT_GELU_ERF);
+    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, Dm, M, Dm, D, act);
       CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
-    { VtGemmParams p = lin(ws + w.h1, d.adt, 4 * D, L.fc2_w, d.cdt, 4 * D, L.fc2_b, tok, VT_F32, D, M, D, 4 * D, VT_ACT_NONE);
+    { VtGemmParams p = lin(ws + w.h1, d.adt, Dm, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, D, M, D, Dm, VT_ACT_NONE);
       p.colscale = L.ls2; p.residual = tok; p.ldr = D;
       CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2")); }
   }
-  // 3. final LayerNorm on the CLS rows only -> pooler_output
-  CK(vt_k_rownorm(tok, VT_F32, (long)N * D, out, VT_F32, D, h->lnf_w, h->lnf_b, Bt, D, d.eps, VT_NORM_LAYER, s));
+  // 3. final LayerNorm: on the CLS rows only -> pooler_output (DINOv2), or on every token -> last_hidden_state (SigLIP)
+  if (d.out_all) CK(vt_k_rownorm(tok, VT_F32, D, out, VT_F32, D, h->lnf_w, h->lnf_b, M, D, d.eps, VT_NORM_LAYER, s));
+  else CK(vt_k_rownorm(tok, VT_F32, (long)N * D, out, VT_F32, D, h->lnf_w, h->lnf_b, Bt, D, d.eps, VT_NORM_LAYER, s));
   return VT_OK;
 }
 

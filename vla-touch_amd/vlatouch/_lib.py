@@ -65,7 +65,7 @@ class AttnParams(C.Structure):
         ("o_bs", C.c_long), ("o_rs", C.c_long),
         ("kmask", C.c_void_p), ("km_bs", C.c_long),
         ("B", C.c_int), ("H", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int),
-        ("scale", C.c_float), ("dtype", C.c_int),
+        ("scale", C.c_float), ("dtype", C.c_int), ("hd", C.c_int),
     ]
 
 
@@ -77,7 +77,9 @@ class UnetDesc(C.Structure):
 
 class DinoDesc(C.Structure):
     _fields_ = [("hidden", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("patch", C.c_int), ("kpad", C.c_int),
-                ("cdt", C.c_int), ("adt", C.c_int), ("eps", C.c_float)]
+                ("cdt", C.c_int), ("adt", C.c_int), ("eps", C.c_float),
+                ("no_cls", C.c_int), ("act", C.c_int), ("head_dim", C.c_int), ("mlp_dim", C.c_int), ("out_all", C.c_int),
+                ("attn_scale", C.c_float)]
 
 
 class LstmDesc(C.Structure):

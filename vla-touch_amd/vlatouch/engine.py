@@ -296,6 +296,115 @@ class DinoEngine:
         return out
 
 
+# =========================================================================================== SigLIP image tokens
+class SiglipEngine:
+    """HF SiglipVisionModel state dict -> last_hidden_state [B, tokens, hidden] (the RDT image tower).
+
+    Runs on the same ViT driver as DINOv2 (vt_dino_*): no CLS token, tanh-GELU, every token through the final LayerNorm.
+    The 72-wide heads are packed zero-padded to 96 (q/k/v rows, out_proj columns) so the head_dim-96 attention kernel and the
+    K % 64 GEMM tiles apply; the FFN width (4304) is zero-padded to a multiple of 64 (gelu(0) = 0, zero fc2 columns)."""
+
+    HD_PAD = 96
+
+    def __init__(self, sd: SD, *, heads: int, precision: str = "fp32", device="cuda", patch: int = 14, eps: float = 1e-6):
+        self.device = L.require_gpu(device)
+        cdt, adt = precision_dtypes(precision)
+        self.cdt, self.adt = cdt, adt
+        wdt = L.torch_dtype(cdt)
+        if any(k.startswith("vision_model.") for k in sd):
+            sd = {k[len("vision_model."):]: v for k, v in sd.items() if k.startswith("vision_model.")}
+        g = lambda k: sd[k].detach().float().cpu()
+        pw = g("embeddings.patch_embedding.weight")
+        D = pw.shape[0]
+        hd = D // heads
+        if hd * heads != D or hd > self.HD_PAD or D % 64:
+            raise L.VtError(f"SiglipEngine: hidden {D} / heads {heads} not supported (head_dim <= 96, hidden % 64 == 0)")
+        HP = self.HD_PAD if hd != 64 else 64
+        Da = heads * HP
+        self.hidden, self.heads, self.patch, self.head_dim = D, heads, patch, hd
+        self.kpad = _pad_to(3 * patch * patch, 16 if cdt == L.F32 else 64)
+        layers = 0
+        while f"encoder.layers.{layers}.layer_norm1.weight" in sd:
+            layers += 1
+        self.layers = layers
+        inter = g("encoder.layers.0.mlp.fc1.weight").shape[0]
+        Dm = _pad_to(inter, 64)
+        dev = self.device
+        pwp = torch.zeros(D, self.kpad)
+        pwp[:, : 3 * patch * patch] = pw.reshape(D, -1)
+        self._pos = g("embeddings.position_embedding.weight").contiguous().to(dev)          # [n_pos, D] fp32
+        ones = torch.ones(D)
+
+        def pad_rows(w):          # [D, K] (rows = heads x hd) -> [Da, K]
+            out = torch.zeros(heads, HP, w.shape[1])
+            out[:, :hd] = w.reshape(heads, hd, w.shape[1])
+            return out.reshape(Da, w.shape[1])
+
+        def pad_vec(b):
+            out = torch.zeros(heads, HP)
+            out[:, :hd] = b.reshape(heads, hd)
+            return out.reshape(Da)
+
+        W: List[torch.Tensor] = [pwp.to(wdt).to(dev), g("embeddings.patch_embedding.bias").to(dev), torch.zeros(D).to(dev)]
+        for i in range(layers):
+            p = f"encoder.layers.{i}"
+            a = f"{p}.self_attn"
+            qkv_w = torch.cat([pad_rows(g(f"{a}.q_proj.weight")), pad_rows(g(f"{a}.k_proj.weight")), pad_rows(g(f"{a}.v_proj.weight"))], dim=0)
+            qkv_b = torch.cat([pad_vec(g(f"{a}.q_proj.bias")), pad_vec(g(f"{a}.k_proj.bias")), pad_vec(g(f"{a}.v_proj.bias"))], dim=0)
+            ow = g(f"{a}.out_proj.weight")                                                   # [D, D] columns = heads x hd
+            owp = torch.zeros(D, heads, HP)
+            owp[:, :, :hd] = ow.reshape(D, heads, hd)
+            fc1 = torch.zeros(Dm, D)
+            fc1[:inter] = g(f"{p}.mlp.fc1.weight")
+            fc1b = torch.zeros(Dm)
+            fc1b[:inter] = g(f"{p}.mlp.fc1.bias")
+            fc2 = torch.zeros(D, Dm)
+            fc2[:, :inter] = g(f"{p}.mlp.fc2.weight")
+            W += [g(f"{p}.layer_norm1.weight").to(dev), g(f"{p}.layer_norm1.bias").to(dev), qkv_w.to(wdt).contiguous().to(dev), qkv_b.to(dev),
+                  owp.reshape(D, Da).to(wdt).contiguous().to(dev), g(f"{a}.out_proj.bias").to(dev), ones.to(dev),
+                  g(f"{p}.layer_norm2.weight").to(dev), g(f"{p}.layer_norm2.bias").to(dev),
+                  fc1.to(wdt).to(dev), fc1b.to(dev), fc2.to(wdt).to(dev), g(f"{p}.mlp.fc2.bias").to(dev), ones.to(dev)]
+        W += [g("post_layernorm.weight").to(dev), g("post_layernorm.bias").to(dev)]
+        W = [w.contiguous() for w in W]
+        self._weights = W
+        desc = L.DinoDesc()
+        desc.hidden, desc.layers, desc.heads, desc.patch, desc.kpad = D, layers, heads, patch, self.kpad
+        desc.cdt, desc.adt, desc.eps = cdt, adt, eps
+        desc.no_cls, desc.act, desc.head_dim, desc.mlp_dim, desc.out_all = 1, L.ACT_GELU_TANH, HP, Dm, 1
+        desc.attn_scale = float(hd) ** -0.5
+        lib = L.lib()
+        assert lib.vt_dino_num_weights(C.byref(desc)) == len(W)
+        self._h = C.c_void_p()
+        L.check(lib.vt_dino_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_dino_create (siglip)")
+        self._ws = _Workspace(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                L.lib().vt_dino_destroy(self._h)
+        except Exception:
+            pass
+
+    @property
+    def num_patches(self) -> int:
+        return self._pos.shape[0]
+
+    def forward(self, pixel_values: torch.Tensor) -> torch.Tensor:
+        """pixel_values [B, 3, res, res] (already rescaled + normalised by the image processor) -> [B, tokens, hidden] fp32."""
+        x = pixel_values.to(self.device, torch.float32).contiguous()
+        B, _, res, res2 = x.shape
+        grid = res // self.patch
+        if res != res2 or grid * grid != self._pos.shape[0]:
+            raise L.VtError(f"SiglipEngine: {res}x{res2} input does not match the {self._pos.shape[0]}-entry position table")
+        out = torch.empty(B, grid * grid, self.hidden, dtype=torch.float32, device=self.device)
+        flags = torch.empty(1, 4, dtype=torch.float32, device=self.device)
+        lib = L.lib()
+        ws = self._ws.get(lib.vt_dino_workspace_bytes(self._h, B, res))
+        L.check(lib.vt_dino_forward(self._h, L.ptr_array([x]), 1, 0, 0, C.c_float(1.0), L.IMGNORM_OFF, B, res, L.ptr(self._pos), L.ptr(out),
+                                    L.ptr(flags), L.ptr(ws), L.stream_ptr(self.device)), "vt_dino_forward (siglip)")
+        return out
+
+
 # =========================================================================================== MLP chain
 class MlpEngine:
     """nn.Sequential(Linear, act, Linear, act, ..., Linear) with torch-style keys '0.weight', '2.weight', ..."""

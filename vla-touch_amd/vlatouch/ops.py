@@ -73,23 +73,24 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
               kmask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [B,Nq,H,64], k/v [B,Nk,H,64] (any strides with unit inner stride) -> [B,Nq,H*64].  kmask [B,Nk] bool."""
+    """q [B,Nq,H,hd], k/v [B,Nk,H,hd], hd 64 or 96 (any strides with unit inner stride) -> [B,Nq,H*hd].  kmask [B,Nk] bool."""
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
-    assert hd == 64 and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
-    o = torch.empty(B, Nq, H * 64, dtype=q.dtype, device=q.device)
+    assert hd in (64, 96) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    o = torch.empty(B, Nq, H * hd, dtype=q.dtype, device=q.device)
     p = L.AttnParams()
     p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
     p.q_bs, p.q_rs, p.q_hs = q.stride(0), q.stride(1), q.stride(2)
     p.k_bs, p.k_rs, p.k_hs = k.stride(0), k.stride(1), k.stride(2)
     p.v_bs, p.v_rs, p.v_hs = v.stride(0), v.stride(1), v.stride(2)
-    p.o_bs, p.o_rs = Nq * H * 64, H * 64
+    p.o_bs, p.o_rs = Nq * H * hd, H * hd
+    p.hd = hd
     km = None
     if kmask is not None:
         km = kmask.to(torch.uint8).contiguous()
         p.kmask, p.km_bs = km.data_ptr(), Nk
     p.B, p.H, p.Nq, p.Nk = B, H, Nq, Nk
-    p.scale = scale if scale is not None else 64 ** -0.5
+    p.scale = scale if scale is not None else hd ** -0.5
     p.dtype = L.dt_code(q.dtype)
     L.check(L.lib().vt_attention(C.byref(p), L.stream_ptr(q.device)), "vt_attention")
     return o

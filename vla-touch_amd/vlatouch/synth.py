@@ -291,3 +291,40 @@ def rdt_runner_shapes(*, hidden: int, depth: int, heads: int, horizon: int, acti
     d.update(_adaptor_shapes("img_adaptor", img_adaptor, img_token_dim, D))
     d.update(_adaptor_shapes("state_adaptor", state_adaptor, state_token_dim * 2, D))
     return d
+
+
+SIGLIP_CONFIGS = {
+    # google/siglip-so400m-patch14-384 (the RDT image tower, models/multimodal_encoder/siglip_encoder.py): 16 heads of 72
+    "so400m": dict(hidden=1152, layers=27, heads=16, inter=4304, image_size=384),
+    # test-size variants that keep the 72-wide heads and a hidden size the MFMA kernels accept (multiple of 64)
+    "tiny": dict(hidden=576, layers=2, heads=8, inter=1072, image_size=56),
+    "wide2": dict(hidden=1152, layers=2, heads=16, inter=4304, image_size=98),
+}
+
+
+def siglip_shapes(hidden: int, layers: int, inter: int, image_size: int = 384, patch: int = 14, **_) -> Dict[str, Tuple[int, ...]]:
+    """HF SiglipVisionModel key map (transformers 5.x spelling, no `vision_model.` prefix), without the pooling head: the RDT
+    tower returns last_hidden_state (siglip_encoder.py:33-35)."""
+    D = hidden
+    n_pos = (image_size // patch) ** 2
+    d: Dict[str, Tuple[int, ...]] = {
+        "embeddings.patch_embedding.weight": (D, 3, patch, patch),
+        "embeddings.patch_embedding.bias": (D,),
+        "embeddings.position_embedding.weight": (n_pos, D),
+    }
+    for i in range(layers):
+        p = f"encoder.layers.{i}"
+        d[f"{p}.layer_norm1.weight"] = (D,)
+        d[f"{p}.layer_norm1.bias"] = (D,)
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            d[f"{p}.self_attn.{n}.weight"] = (D, D)
+            d[f"{p}.self_attn.{n}.bias"] = (D,)
+        d[f"{p}.layer_norm2.weight"] = (D,)
+        d[f"{p}.layer_norm2.bias"] = (D,)
+        d[f"{p}.mlp.fc1.weight"] = (inter, D)
+        d[f"{p}.mlp.fc1.bias"] = (inter,)
+        d[f"{p}.mlp.fc2.weight"] = (D, inter)
+        d[f"{p}.mlp.fc2.bias"] = (D,)
+    d["post_layernorm.weight"] = (D,)
+    d["post_layernorm.bias"] = (D,)
+    return d
