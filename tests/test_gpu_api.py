@@ -160,3 +160,40 @@ def test_no_cpu_fallback():
     from vlatouch import _lib
     with pytest.raises(_lib.VtError):
         _lib.require_gpu("cpu")
+
+
+@pytest.mark.parametrize("B,T,res,layout", [(1, 32, 384, "bthwc"), (3, 8, 224, "uint8_bhwc"), (5, 4, 224, "bchw"), (2, 16, 518, "bchw")])
+def test_predict_edge_shapes_vs_oracle(controllers, B, T, res, layout):
+    """Shapes off the golden set, against the oracle run live: BASELINE configs[0] (batch 1, T = 32, 384x384 frames in the
+    reference's 5-D [B,1,H,W,3] layout), odd batches, the shortest horizon the U-Net accepts (T = 4), uint8 BHWC frames (the
+    /255 branch) and the native 518 resolution (no position-embedding interpolation)."""
+    from oracle import controller as oc
+    ctrl = controllers["fp32"]
+    g = np.random.default_rng(100 + B)
+    state = torch.from_numpy(g.standard_normal((B, 10)).astype(np.float32))
+    forces = torch.from_numpy(g.standard_normal((B, 3)).astype(np.float32))
+    vla = torch.from_numpy(g.uniform(0, 1, (B, T, 10)).astype(np.float32))
+    z = torch.from_numpy(g.standard_normal((10, B, T, 10)).astype(np.float32))
+    u1, u2 = 0.2 + 0.8 * g.random((B, 3, res, res)), 0.6 * g.random((B, 3, res, res))
+    if layout == "bchw":
+        cam1, cam2 = torch.from_numpy(u1.astype(np.float32)), torch.from_numpy(u2.astype(np.float32))
+    elif layout == "uint8_bhwc":
+        cam1 = torch.from_numpy((255 * u1).astype(np.uint8).transpose(0, 2, 3, 1).copy())
+        cam2 = torch.from_numpy((255 * u2).astype(np.uint8).transpose(0, 2, 3, 1).copy())
+    else:
+        cam1 = torch.from_numpy(u1.astype(np.float32).transpose(0, 2, 3, 1)[:, None].copy())
+        cam2 = torch.from_numpy(u2.astype(np.float32).transpose(0, 2, 3, 1)[:, None].copy())
+    ref = oc.predict(cases.dino_sd("small"), 6, cases.state_encoder_sd(781), cases.si_net_sd("ema"), cases.stats("nontrivial"),
+                     state, vla, cam1, cam2, forces, z)
+    got = ctrl.predict(state.cuda(), vla.cuda(), cam1.cuda(), cam2.cuda(), forces.cuda(), noise=z.cuda())
+    assert got.shape == (B, T, 10)
+    assert err(got, ref.numpy()) < TOL["fp32"], err(got, ref.numpy())
+
+
+def test_predict_rejects_horizons_the_unet_cannot_run(controllers):
+    """T must be divisible by 4 (two stride-2 downsamplings, conditional_unet_1D.py): the reference fails inside torch.cat on
+    the skip connection; here the driver refuses up front."""
+    ctrl = controllers["fp32"]
+    inp = cases.predict_inputs(2, 16, 224)
+    with pytest.raises(Exception):
+        ctrl.predict(inp["state"].cuda(), inp["vla"][:, :6].cuda(), inp["cam1"].cuda(), inp["cam2"].cuda(), inp["forces"].cuda())

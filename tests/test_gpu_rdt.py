@@ -178,3 +178,27 @@ def test_rdt_condition_cache_written_by_gemm_epilogues(img_len):
     print(f"[img_len {img_len}] scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |ref16-exact| {e_ref:.3e}")
     assert torch.isfinite(y.float()).all()
     assert e_hip <= max(1e-2 * scale, 1.5 * e_ref), (e_hip, e_ref)
+
+
+@pytest.mark.parametrize("dname,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+@pytest.mark.parametrize("B,L,valid", [(1, 1, 1), (3, 16, 1), (2, 16, 16), (5, 7, 4)])
+def test_rdt_forward_edge_language_lengths(dname, dtype, B, L, valid):
+    """Language conditions at the edges, against the oracle run live: a single token, the maximum length, samples with only
+    `valid` unmasked tokens (the reference passes -inf masks to SDPA, blocks.py:116-123), odd batch sizes."""
+    from oracle import rdt as orr
+    cfg = cases.RDT_TINY
+    m = make_rdt(cfg, dtype)
+    ri = cases.rdt_inputs(cfg, B, L, seed=20 + B, dtype=dtype)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[:, :valid] = True
+    mask[-1, :] = True                                     # last sample fully valid
+    ri["lang_mask"] = mask
+    y = m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"])
+    sd = cases.rdt_sd(cfg, torch.float32)
+    rf = {k: (v.float() if v.is_floating_point() else v) for k, v in ri.items()}
+    exact = orr.rdt_forward(sd, rf["x"], rf["freq"], rf["t"], rf["lang_c"], rf["img_c"], lang_mask=rf["lang_mask"], heads=cfg["heads"],
+                            horizon=cfg["horizon"])
+    assert y.shape == exact.shape and torch.isfinite(y.float()).all()
+    scale = max(1.0, float(exact.abs().max()))
+    e = err(y, exact.numpy())
+    assert e < (2e-4 if dname == "f32" else 3e-2) * scale, (dname, B, L, valid, e)
