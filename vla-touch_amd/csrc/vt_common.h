@@ -88,17 +88,24 @@ __device__ __forceinline__ void lds_frag(Frag<float>& f, const char* tile, int r
   f.v[4] = hi[0]; f.v[5] = hi[1]; f.v[6] = hi[2]; f.v[7] = hi[3];
 }
 
+// exp(x) on the hardware exp2 unit (v_exp_f32, ~1 ulp): the activations below are evaluated per output element of GEMM / GroupNorm
+// epilogues, where libm's tanhf / log1pf / expf (30-60 instructions each) cost more than the GEMM's k-loop saves
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
 __device__ __forceinline__ float act_apply(float x, int act) {
   switch (act) {
     case VT_ACT_GELU_ERF: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
     case VT_ACT_GELU_TANH: {
-      const float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-      return 0.5f * x * (1.0f + tanhf(u));
+      // 0.5 x (1 + tanh(u)) == x * sigmoid(2u), u = sqrt(2/pi) (x + 0.044715 x^3)
+      const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
+      return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-u2));
     }
-    case VT_ACT_SILU: return x / (1.0f + expf(-x));
+    case VT_ACT_SILU: return x * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x));
     case VT_ACT_MISH: {
-      const float sp = x > 20.0f ? x : log1pf(expf(x));
-      return x * tanhf(sp);
+      // x tanh(log(1 + e^x)) == x w / (w + 2), w = e^x (e^x + 2)   (tanh(log s) = (s^2 - 1) / (s^2 + 1), s = 1 + e^x)
+      if (x > 20.0f) return x;
+      const float n = fast_exp(x), w = n * (n + 2.0f);
+      return x * w * __builtin_amdgcn_rcpf(w + 2.0f);
     }
     default: return x;
   }
