@@ -116,7 +116,7 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
     } else {
       // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
       if (p.act != VT_ACT_NONE) {
-#pragma unroll 1
+#pragma unroll 2
         for (int it = 0; it < nrows / 4; ++it) {
           const int row = it * 4 + (lane >> 4);
           const float4 x = *reinterpret_cast<const float4*>(ep + row * EP_LD + c4 * 4);

@@ -10,8 +10,9 @@
 //   * the DMA of a group's next k-tile has a whole MFMA phase to land: the wave waits for its own pieces at the end of that
 //     phase, the closing barrier makes them block-visible, the following memory phase reads them (RAW); a buffer is restaged
 //     two of the group's k-tiles after its last read (WAR);
-//   * at the end group 1 hands its accumulators over through LDS (80 KiB, lane-contiguous), group 0 adds them (a + b is
-//     commutative: the result does not depend on timing) and runs the shared epilogue.
+//   * at the end the groups swap halves of their accumulators through LDS (80 KiB, lane-contiguous): group 0 finishes row tiles
+//     0..2 of every wave tile, group 1 row tiles 3..4 (a + b is commutative: the result does not depend on timing), and both
+//     run the shared epilogue on their part.
 #include <stdlib.h>
 #include "vt_common.h"
 #include "vt_gemm.h"
@@ -31,7 +32,9 @@ constexpr int BUF_BYTES = (BM + BN) * 128;       // one k-tile: A rows 0..159 th
 
 template <typename T16, typename TC>
 __global__ __launch_bounds__(512, 2) void gemm_ppk_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * BUF_BYTES];        // [group][stage]
+  constexpr int XCH_BYTES = 4 * (4 * TM * 4) * 64 * 4;                       // accumulator hand-over area (80 KiB)
+  constexpr int SMEM = 4 * BUF_BYTES > XCH_BYTES + 8 * EP_BYTES ? 4 * BUF_BYTES : XCH_BYTES + 8 * EP_BYTES;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];                 // [group][stage] operand buffers; later hand-over area + 8 patches
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp_k = wave >> 2, wq = wave & 3;      // k-parity group, wave inside the group
@@ -123,26 +126,44 @@ __global__ __launch_bounds__(512, 2) void gemm_ppk_kernel(const VtGemmParams p, 
   if (grp_k == 0) __builtin_amdgcn_s_barrier();   // pay back the stagger
   __syncthreads();                                // every fragment read is done: the buffers become the hand-over area
 
-  // ---- group 1 -> group 0 through LDS: [wq][register][lane] floats (lane-contiguous: conflict-free), 4 x 80 x 64 x 4 B = 80 KiB
+  // ---- the groups swap halves through LDS ([wq][register][lane] floats, lane-contiguous: conflict-free; 4 x 80 x 64 x 4 B =
+  // 80 KiB): group 0 ends up with the summed row tiles 0..2 of every wave tile, group 1 with row tiles 3..4, and BOTH run the
+  // shared epilogue on their part (it is a third of this kernel's time at K = 2048: bias / norm / activation / residual on
+  // 160 x 128 outputs with one block per CU and nothing else to overlap it with).  a + b is commutative: the result does not
+  // depend on which group adds.
+  constexpr int T0 = 3, T1 = TM - T0;              // row tiles finished by group 0 / group 1
   float* xch = reinterpret_cast<float*>(smem) + (long)wq * (4 * TM * 4) * 64 + lane;
-  if (grp_k == 1) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) xch[((i * TM + j) * 4 + r) * 64] = acc[i][j][r];
-  }
-  __syncthreads();
-  if (grp_k == 1) return;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
+    for (int j = 0; j < TM; ++j) {
+      const bool mine = grp_k == 0 ? (j < T0) : (j >= T0);
+      if (!mine) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] += xch[((i * TM + j) * 4 + r) * 64];
-  // group 0's waves reuse the tail of the LDS (beyond the hand-over area) as epilogue patches: no further block barrier
-  vt_gemm_epilogue<TC, TM, 0>(p, acc, reinterpret_cast<float*>(smem + 3 * BUF_BYTES + wq * EP_BYTES), grp, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+        for (int r = 0; r < 4; ++r) xch[((i * TM + j) * 4 + r) * 64] = acc[i][j][r];
+      }
+    }
+  __syncthreads();
+  float* ep = reinterpret_cast<float*>(smem + XCH_BYTES + wave * EP_BYTES);      // private patch beyond the hand-over area (others may still read it)
+  if (grp_k == 0) {
+    float4_t part[4][T0];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < T0; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[i][j][r] = acc[i][j][r] + xch[((i * TM + j) * 4 + r) * 64];
+    vt_gemm_epilogue<TC, T0, 0>(p, part, ep, grp, m0 + wm * (BM / 2), n0 + wn * 64, lane);
+  } else {
+    float4_t part[4][T1];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < T1; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[i][j][r] = acc[i][T0 + j][r] + xch[((i * TM + T0 + j) * 4 + r) * 64];
+    vt_gemm_epilogue<TC, T1, 0>(p, part, ep, grp, m0 + wm * (BM / 2) + T0 * 16, n0 + wn * 64, lane);
+  }
 }
 
 }  // namespace
