@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef uint16_t bf16_t;  // raw bits
 typedef __attribute__((ext_vector_type(8))) short short8_t;
@@ -114,6 +115,19 @@ __device__ __forceinline__ float act_apply(float x, int act) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+// sum over each aligned group of 16 lanes, result in every lane, on DPP lane permutes only (no LDS crossbar round trips as
+// __shfl_xor would take): pairs inside quads, quads inside 8s (row_half_mirror pairs quad 0 <-> quad 1), 8s inside the row of 16
+// (row_mirror); for a sum any pairing that covers the group works.
+__device__ __forceinline__ float row16_sum(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {

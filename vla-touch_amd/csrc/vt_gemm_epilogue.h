@@ -22,8 +22,8 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
   if (hw) {   // per-head RMSNorm over the row's 64 columns = the 16 lanes sharing lane>>4 (wave-uniform branch; all lanes shuffle)
     float s = o[0] + o[1] + o[2] + o[3];
     float q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { s += __shfl_xor(s, d, 64); q += __shfl_xor(q, d, 64); }
+    s = row16_sum(s);
+    q = row16_sum(q);
     float var;
     if (p.hn_mode == 2) { const float mean = s * (1.f / 64.f); var = (q - 64.f * mean * mean) * (1.f / 63.f); }
     else var = q * (1.f / 64.f);
