@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ppk_kernel(const VtGemmParams p, 
 bool vt_gemm_ppk_eligible(const VtGemmParams& p) {
   if (!vt_gemm_fast_eligible(p) || p.cmap) return false;
   const long tiles = (long)((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.groups;
-  return tiles >= 120 && tiles <= 256 && p.K >= 512;     // one round of 160 x 128 tiles over the 256 CUs
+  return tiles >= 100 && tiles <= 256 && p.K >= 512;     // one round of 160 x 128 tiles over the 256 CUs
 }
 
 int vt_gemm_ppk_launch(const VtGemmParams& p, hipStream_t s) {
