@@ -11,7 +11,8 @@
  * stream — all work is enqueued on `stream` (a hipStream_t).  Return value: 0 on success, negative
  * errno-style code otherwise (-22 bad argument, -95 unsupported, -5 launch failure);
  * vt_last_error() returns a host string for the last failure on the calling thread.
- * dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit).  "cdt" = compute/storage dtype of weights,
+ * dtype codes: 0 = fp32, 1 = bf16 (raw 16-bit), 2 = fp32 storage with split-bf16 compute (GEMM weights only), 3 = IEEE fp16.
+ * "cdt" = compute/storage dtype of weights,
  * "adt" = dtype of activations between kernels.
  */
 #ifndef VLATOUCH_H
@@ -45,7 +46,7 @@ int vt_prof_collect(double* total_ms, double* flops, double* bytes, long* launch
  * Replaces torch nn.Linear / nn.Conv1d / nn.ConvTranspose1d calls of
  * bridge/networks/conditional_unet_1D.py:25,34,49,83, bridge_controller.py:42-48, HF Dinov2 linears. */
 int vt_gemm(const void* params, vt_stream_t stream);
-/* Flash attention, head_dim 64: params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
+/* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
  * Replaces F.scaled_dot_product_attention (models/rdt/blocks.py:116-123) and HF Dinov2SelfAttention. */
 int vt_attention(const void* params, vt_stream_t stream);
 /* GroupNorm(+Mish, FiLM, residual) over fp32 split-K slabs: params = struct VtGnParams. */

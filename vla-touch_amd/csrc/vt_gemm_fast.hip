@@ -11,10 +11,8 @@
 // before the MFMAs of tile t).  Blocks are dealt to XCDs in contiguous bands of tiles, and inside a band in super-rows of
 // GM m-tiles, so neighbouring tiles share operand panels in that XCD's private L2.
 // Operands are swapped (D = W_tile A_tile^T) so a lane ends with 4 consecutive n of one row m.
-// Epilogue: + bias, optional per-head RMSNorm (q_norm / k_norm of timm Attention: a wave's 64 columns are exactly
-// one head, the row's 64 values live in the 4 lanes sharing lane&15 -> two shuffles), activation, column scale
-// (LayerScale); then the wave's sub-tile goes through a private LDS patch and is written (and the residual read) as
-// WHOLE 256-B / 128-B row segments — the MFMA register layout alone would scatter 32-B pieces over 16 rows per store.
+// Epilogue: vt_gemm_epilogue.h (shared with the ping-pong kernels vt_gemm_pp.hip / vt_gemm_ppk.hip, which take the shapes
+// their tiles fit: this kernel is the fallback for every other large 16-bit GEMM).
 #include <stdlib.h>
 #include "vt_common.h"
 #include "vt_gemm.h"
