@@ -197,3 +197,52 @@ def test_predict_rejects_horizons_the_unet_cannot_run(controllers):
     inp = cases.predict_inputs(2, 16, 224)
     with pytest.raises(Exception):
         ctrl.predict(inp["state"].cuda(), inp["vla"][:, :6].cuda(), inp["cam1"].cuda(), inp["cam2"].cuda(), inp["forces"].cuda())
+
+
+def test_predict_and_rdt_chunk_are_graph_capturable(controllers):
+    """The C ABI promises: no allocation, no synchronisation, everything on the caller's stream.  So a whole predict() (and an RDT
+    predict_action) must be capturable in a hipGraph after one warm-up call sized the workspaces, and replays must reproduce the
+    eager result bit for bit (how bench.py runs the step)."""
+    from models.rdt_runner import RDTRunner
+    ctrl = controllers["bf16"]
+    inp = {k: v.cuda() for k, v in cases.predict_inputs(4, 16, 224).items()}
+    z = inp["z"].repeat(1, 2, 1, 1)[:, :4].contiguous()
+    eager = ctrl.predict(inp["state"][:4] if inp["state"].shape[0] >= 4 else inp["state"].repeat(2, 1), inp["vla"].repeat(2, 1, 1)[:4],
+                         inp["cam1"].repeat(2, 1, 1, 1)[:4], inp["cam2"].repeat(2, 1, 1, 1)[:4], inp["forces"].repeat(2, 1)[:4], noise=z)
+    args = (inp["state"].repeat(2, 1)[:4].contiguous(), inp["vla"].repeat(2, 1, 1)[:4].contiguous(), inp["cam1"].repeat(2, 1, 1, 1)[:4].contiguous(),
+            inp["cam2"].repeat(2, 1, 1, 1)[:4].contiguous(), inp["forces"].repeat(2, 1)[:4].contiguous())
+    stream = torch.cuda.Stream()
+    holder = {}
+    with torch.cuda.stream(stream):
+        holder["out"] = ctrl.predict(*args, noise=z)           # warm-up on the capture stream
+        stream.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=stream):
+            holder["out"] = ctrl.predict(*args, noise=z)
+        for _ in range(2):
+            g.replay()
+        stream.synchronize()
+    assert torch.equal(holder["out"], eager)
+    # RDT chunk (tiny config), noise injected
+    cfg = cases.RDT_TINY
+    c = {"rdt": {"hidden_size": cfg["hidden"], "depth": cfg["depth"], "num_heads": cfg["heads"]}, "lang_adaptor": "mlp2x_gelu",
+         "img_adaptor": "mlp2x_gelu", "state_adaptor": "mlp3x_gelu",
+         "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": 5, "beta_schedule": "squaredcos_cap_v2",
+                             "prediction_type": "sample", "clip_sample": False}}
+    r = RDTRunner(action_dim=cfg["action_dim"], pred_horizon=cfg["horizon"], config=c, lang_token_dim=cfg["lang_token_dim"],
+                  img_token_dim=cfg["img_token_dim"], state_token_dim=cfg["state_token_dim"], max_lang_cond_len=cfg["max_lang_cond_len"],
+                  img_cond_len=cfg["img_cond_len"], dtype=torch.bfloat16, device="cuda:0")
+    r.load_state_dict(cases.rdt_sd(cfg, torch.float32))
+    ri = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in cases.rdt_inputs(cfg, 2, 12, dtype=torch.bfloat16).items()}
+    call = lambda: r.predict_action(ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"].cuda(),
+                                    x_init=ri["x_init"])
+    eager = call()
+    with torch.cuda.stream(stream):
+        holder["rdt"] = call()
+        stream.synchronize()
+        g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g2, stream=stream):
+            holder["rdt"] = call()
+        g2.replay()
+        stream.synchronize()
+    assert torch.equal(holder["rdt"], eager)
