@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dino", default="base", choices=["small", "base"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip"],
+    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm"],
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
@@ -134,6 +134,16 @@ def main():
         amask[:, :, :10] = 1.0                                       # the 10 EEF dims of the unified action vector
         rin = dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
                    state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
+    lstm = lstm_in = None
+    if args.workload == "lstm":         # the alternative residual head: obs encoding + T sequential LSTM ticks per chunk
+        from residual_controller.lstm_step_controller import TactileLSTMController
+        lstm = TactileLSTMController(device=dev, precision=args.precision, image_model_path=f"facebook/dinov2-{args.dino}",
+                                     image_state_dict=cases.dino_sd(args.dino))
+        for name, sd in cases.lstm_mods(768 if args.dino == "base" else 384).items():
+            getattr(lstm, name).load_state_dict(sd)
+        lstm.to(dev)
+        lstm.stats = {k: v.to(dev) for k, v in cases.stats("unit").items()}
+        lstm_in = dict(forces=torch.randn(B, T, 3, device=dev))
     sig = sig_px = None
     if args.workload == "siglip":       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
         from vlatouch import synth
@@ -147,6 +157,10 @@ def main():
     setup_s = time.time() - t0
 
     def step():
+        if args.workload == "lstm":
+            obs = lstm.encode_observation(inp["state"], inp["cam1"], inp["cam2"])
+            out_holder["out"] = lstm.predict_sequence(obs, inp["vla"], lstm_in["forces"])
+            return
         if args.workload == "siglip":
             out_holder["out"] = sig.forward(sig_px)
             return
@@ -241,6 +255,8 @@ def main():
                       "pi_refine: 2x DINOv2-%s CLS @%d + state/force MLP + 10-step interpolant SDE (v_net+s_net), T=%d; BASELINE configs[3] "
                       "WITHOUT the RDT-1B chunk generator" % (args.dino, args.res, T)),
         "dino_mlp": ("encoded observations/sec", "dino_mlp = BASELINE configs[1]: 2x DINOv2-%s @%d + state/force MLP" % (args.dino, args.res)),
+        "lstm": ("refined action chunks/sec (LSTM residual head, no RDT chunk generation)", "lstm (SURVEY 8a-7): 2x DINOv2-%s CLS @%d + obs MLP + "
+                 "%d sequential ticks of force MLP -> 2-layer LSTM -> residual head per chunk" % (args.dino, args.res, T)),
         "siglip": ("chunks' worth of image tokens/sec (6 frames per chunk)", "siglip (SURVEY 8f-1): SigLIP-so400m-patch14-384 tower, 6 x 384x384 frames per "
                    "chunk -> 6 x 729 x 1152 image tokens, batch %d chunks (%d images per step)" % (B, 6 * B)),
         "rdt": ("RDT-1B action chunks/sec", "rdt = BASELINE configs[2] shape: RDT-1B, %d-step DPM-Solver++, cached T5-sized (4096-d) language "
