@@ -213,6 +213,36 @@ __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
   }
 }
 
+// ------------------------------------------------------------------ split-K slab reduction + Linear epilogue (small-M GEMMs)
+// out[m, n..n+3] = residual + colscale * act(sum_s slab[s][m][n] + bias): the tail of a GEMM whose k range was split over
+// blocks because M alone gives too few tiles to hide a 2048-deep k-loop (RDT at batch 1-4: M = 67..268 rows).
+template <typename TO>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab_stride, int M, int N, const float* __restrict__ bias,
+                                                          int act, const float* __restrict__ cs, const TO* __restrict__ R, long ldr, TO* __restrict__ out, long ldo) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const int n4 = N >> 2;
+  if (i >= (long)M * n4) return;
+  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s0 = 0; s0 < S; s0 += 4) {            // 4 independent loads in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = s0 + u < S ? *reinterpret_cast<const float4*>(slabs + (long)(s0 + u) * slab_stride + (long)m * N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+  }
+  float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float x = o[r] + (bias ? bias[n + r] : 0.f);
+    x = act_apply(x, act);
+    if (cs) x *= cs[n + r];
+    if (R) x += Elem<TO>::to_f(R[(long)m * ldr + n + r]);
+    out[(long)m * ldo + n + r] = Elem<TO>::from_f(x);
+  }
+}
+
 // ------------------------------------------------------------------ small element-wise kernels
 template <typename TO>
 __global__ void sinusoid_kernel(const float* __restrict__ t, float t_host, TO* __restrict__ out, int B, int dim, int nets, long net_stride, int cos_first, float denom_minus) {
@@ -416,6 +446,15 @@ int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, cons
   const long rows = tokens * heads;
   if (rows <= 0) return VT_ERR_ARG;
   DISPATCH_T(dt, T, hipLaunchKernelGGL((headnorm_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (T*)x, tok_stride, heads, rows, w, eps, mode))
+  return vt_check_launch();
+}
+
+int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
+                     const void* residual, long ldr, void* out, int odt, long ldo, hipStream_t s) {
+  if (S < 1 || (N & 3) || M <= 0) return VT_ERR_ARG;
+  const long n = (long)M * (N >> 2);
+  DISPATCH_T(odt, TO, hipLaunchKernelGGL((slab_reduce_kernel<TO>), g1(n), dim3(256), 0, s, slabs, S, slab_stride, M, N, bias, act, colscale,
+                                         (const TO*)residual, ldr, (TO*)out, ldo))
   return vt_check_launch();
 }
 

@@ -94,10 +94,12 @@ void vt_rdt_destroy(vt_rdt_t h) { delete h; }
 
 namespace {
 inline int lpad64(int L) { return (L + 63) / 64 * 64; }
+constexpr int RDT_MAX_SPLITK = 16;
 struct RWs {
   size_t lang_c, img_c, tmpA, tmpB, state_tok, freq_emb, t_emb, emb_tmp, sin, kv_lang, kv_img, x, xn, qkv, q, att, hid, sa_in, sa_tmpA, sa_tmpB,
-      out_tok, x0_cur, x0_prev, noisy, noisy_a, total;
+      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, total;
   size_t kv_lang_blk, kv_img_blk;   // bytes per block
+  size_t slab_bytes;                // split-K scratch of the small-batch Linears (0 when M is large enough without it)
 };
 RWs rcarve(const vt_rdt_s* h, int B, int L) {
   const vt_rdt_desc& d = h->d;
@@ -124,6 +126,8 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.out_tok = take(M * d.out_dim * a);
   w.x0_cur = take((size_t)B * d.horizon * d.out_dim * a); w.x0_prev = take((size_t)B * d.horizon * d.out_dim * a);
   w.noisy = take((size_t)B * d.horizon * d.out_dim * 4); w.noisy_a = take((size_t)B * d.horizon * d.out_dim * a);
+  w.slab_bytes = M <= 512 ? (size_t)RDT_MAX_SPLITK * M * 3 * D * 4 : 0;
+  w.slab = take(w.slab_bytes);
   w.total = o;
   return w;
 }
@@ -135,6 +139,26 @@ bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1
   if (!vt_gemm_can_fuse_headnorm(p)) return false;
   p.hn_w0 = w0; p.hn_c0_end = c0_end; p.hn_w1 = w1; p.hn_c1_end = c1_end; p.hn_eps = 1e-6f; p.hn_mode = mode;
   return true;
+}
+
+// Linear of the denoise loop.  At small batch (M = B*67 rows below ~512) M x N gives the generic kernel only a few dozen tiles, each
+// walking the whole K = 2048 alone (36 us for 8 MB of weights); the k range is then split over up to 16 blocks per tile into fp32
+// slabs and a second tiny kernel sums them and applies the Linear's epilogue.
+int rgemm(RCtx& c, VtGemmParams p, const char* what) {
+  const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
+  const int nk = p.K / 64;
+  int S = (int)(512 / (tiles64 > 0 ? tiles64 : 1));
+  if (S > RDT_MAX_SPLITK) S = RDT_MAX_SPLITK;
+  if (S > nk / 2) S = nk / 2;
+  const bool small = c.w.slab_bytes > 0 && !vt_gemm_fast_eligible(p) && p.M <= 512 && p.K >= 512 && (p.K % 64) == 0 && (p.N % 4) == 0 && !p.hn_w0 &&
+                     !p.hn_w1 && p.groups == 1 && p.taps == 0 && S >= 2 && (size_t)S * p.M * p.N * 4 <= c.w.slab_bytes;
+  if (!small) return vt_wrap(vt_gemm_launch(p, c.s), what);
+  VtGemmParams q = p;
+  q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
+  q.bias = nullptr; q.act = VT_ACT_NONE; q.colscale = nullptr; q.residual = nullptr;
+  CK(vt_wrap(vt_gemm_launch(q, c.s), what));
+  return vt_wrap(vt_k_slab_reduce((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, p.act, p.colscale, p.residual, p.ldr, p.C, p.c_dtype,
+                                  p.ldc, c.s), what);
 }
 
 // adaptor MLP: Linear (gelu_tanh Linear)*  — final layer writes `dst` (ld = D) with optional per-row-in-sample residual (pos embed)
@@ -250,7 +274,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
       const bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt qkv"));
+      CK(rgemm(c, p, "rdt qkv"));
       if (!fused) {
         CK(vt_k_headnorm(c.ws + c.w.qkv, d.adt, 3 * D, d.heads, M, b.qn, 1e-6f, d.rms_mode, c.s));
         CK(vt_k_headnorm(c.ws + c.w.qkv + (size_t)D * a, d.adt, 3 * D, d.heads, M, b.kn, 1e-6f, d.rms_mode, c.s));
@@ -258,30 +282,30 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     CK(attn(c, c.ws + c.w.qkv, 3 * D, c.ws + c.w.qkv + (size_t)D * a, c.ws + c.w.qkv + (size_t)2 * D * a, 3 * D, N, N, nullptr, c.ws + c.w.att));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt proj")); }
+      CK(rgemm(c, p, "rdt proj")); }
     // --- cross attention against the cached condition K/V
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
       const bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross q"));
+      CK(rgemm(c, p, "rdt cross q"));
       if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
     CK(cross_attn(c, l, lang_mask, N));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt cross proj")); }
+      CK(rgemm(c, p, "rdt cross proj")); }
     // --- FFN (hidden = D, tanh-GELU)
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt fc1")); }
+      CK(rgemm(c, p, "rdt fc1")); }
     { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt fc2")); }
+      CK(rgemm(c, p, "rdt fc2")); }
   }
   CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
   { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt final fc1")); }
+    CK(rgemm(c, p, "rdt final fc1")); }
   { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE);
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt final fc2")); }
+    CK(rgemm(c, p, "rdt final fc2")); }
   return VT_OK;
 }
 
