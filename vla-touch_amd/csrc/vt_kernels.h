@@ -55,8 +55,10 @@ int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, c
 int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode, hipStream_t s);
 int vt_k_groupnorm(const VtGnParams& p, hipStream_t s);
 // out = residual + colscale * act(sum of S fp32 split-K slabs [S][M][N] + bias); residual has the output dtype
+// optional per-head (64 columns) RMSNorm after the bias: hn_w0 for columns [0, hn_c0), hn_w1 for [hn_c0, hn_c1) (then no act / residual use)
 int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
-                     const void* residual, long ldr, void* out, int odt, long ldo, hipStream_t s);
+                     const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
+                     float hn_eps, int hn_mode, hipStream_t s);
 int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);
 int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,

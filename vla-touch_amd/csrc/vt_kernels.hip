@@ -216,13 +216,18 @@ __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
 // ------------------------------------------------------------------ split-K slab reduction + Linear epilogue (small-M GEMMs)
 // out[m, n..n+3] = residual + colscale * act(sum_s slab[s][m][n] + bias): the tail of a GEMM whose k range was split over
 // blocks because M alone gives too few tiles to hide a 2048-deep k-loop (RDT at batch 1-4: M = 67..268 rows).
+// Optional per-head RMSNorm (q_norm / k_norm): a head's 64 columns are the 4 columns of 16 consecutive threads (N % 64 == 0), reduced
+// with DPP; columns [0, hn_c0) use gains w0, [hn_c0, hn_c1) use w1.
 template <typename TO>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab_stride, int M, int N, const float* __restrict__ bias,
-                                                          int act, const float* __restrict__ cs, const TO* __restrict__ R, long ldr, TO* __restrict__ out, long ldo) {
+                                                          int act, const float* __restrict__ cs, const TO* __restrict__ R, long ldr, TO* __restrict__ out, long ldo,
+                                                          const float* __restrict__ hn_w0, const float* __restrict__ hn_w1, int hn_c0, int hn_c1, float hn_eps, int hn_mode) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = N >> 2;
-  if (i >= (long)M * n4) return;
-  const int m = (int)(i / n4), n = (int)(i - (long)m * n4) * 4;
+  const bool live = i < (long)M * n4;
+  if (!live && !hn_w0) return;
+  const long ii = live ? i : (long)M * n4 - 1;         // with a head norm every lane takes part in the DPP reduction
+  const int m = (int)(ii / n4), n = (int)(ii - (long)m * n4) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int s0 = 0; s0 < S; s0 += 4) {            // 4 independent loads in flight
     float4 v[4];
@@ -233,9 +238,25 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     for (int u = 0; u < 4; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
   }
   float o[4] = {acc.x, acc.y, acc.z, acc.w};
+  if (hn_w0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o[r] += bias ? bias[n + r] : 0.f;
+    const float sm = row16_sum((o[0] + o[1]) + (o[2] + o[3]));
+    const float sq = row16_sum((o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]));
+    const float* hw = n < hn_c0 ? hn_w0 : (hn_w1 && n < hn_c1 ? hn_w1 : nullptr);
+    if (hw) {
+      float var;
+      if (hn_mode == 2) { const float mean = sm * (1.f / 64.f); var = (sq - 64.f * mean * mean) * (1.f / 63.f); }
+      else var = sq * (1.f / 64.f);
+      const float rstd = rsqrtf(var + hn_eps);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] *= rstd * hw[(n & 63) + r];
+    }
+    if (!live) return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    float x = o[r] + (bias ? bias[n + r] : 0.f);
+    float x = o[r] + ((bias && !hn_w0) ? bias[n + r] : 0.f);
     x = act_apply(x, act);
     if (cs) x *= cs[n + r];
     if (R) x += Elem<TO>::to_f(R[(long)m * ldr + n + r]);
@@ -428,7 +449,7 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
                  float eps, int mode, hipStream_t s) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
-  if (xdt == VT_F32 && D >= 512 && rows >= 256 && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row
+  if (xdt == VT_F32 && D >= 512 && (rows >= 256 || D >= 1024) && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row (also for few wide rows: latency)
     if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
     else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode);
     else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode);
@@ -450,11 +471,12 @@ int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, cons
 }
 
 int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
-                     const void* residual, long ldr, void* out, int odt, long ldo, hipStream_t s) {
-  if (S < 1 || (N & 3) || M <= 0) return VT_ERR_ARG;
+                     const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
+                     float hn_eps, int hn_mode, hipStream_t s) {
+  if (S < 1 || (N & 3) || M <= 0 || (hn_w0 && (N & 63))) return VT_ERR_ARG;
   const long n = (long)M * (N >> 2);
   DISPATCH_T(odt, TO, hipLaunchKernelGGL((slab_reduce_kernel<TO>), g1(n), dim3(256), 0, s, slabs, S, slab_stride, M, N, bias, act, colscale,
-                                         (const TO*)residual, ldr, (TO*)out, ldo))
+                                         (const TO*)residual, ldr, (TO*)out, ldo, hn_w0, hn_w1, hn_c0, hn_c1, hn_eps, hn_mode))
   return vt_check_launch();
 }
 

@@ -144,7 +144,11 @@ bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1
 // Linear of the denoise loop.  At small batch (M = B*67 rows below ~512) M x N gives the generic kernel only a few dozen tiles, each
 // walking the whole K = 2048 alone (36 us for 8 MB of weights); the k range is then split over up to 16 blocks per tile into fp32
 // slabs and a second tiny kernel sums them and applies the Linear's epilogue.
-int rgemm(RCtx& c, VtGemmParams p, const char* what) {
+// hn_*: head norm to apply when the GEMM did NOT fuse it (p.hn_w0 unset): folded into the slab reduction on the split path, else
+// the caller's vt_k_headnorm kernels run (returns *hn_done = false).
+int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullptr, int hn_c0 = 0, const float* hn_w1 = nullptr, int hn_c1 = 0,
+          bool* hn_done = nullptr) {
+  if (hn_done) *hn_done = false;
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int nk = p.K / 64;
   int S = (int)(512 / (tiles64 > 0 ? tiles64 : 1));
@@ -157,8 +161,10 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what) {
   q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
   q.bias = nullptr; q.act = VT_ACT_NONE; q.colscale = nullptr; q.residual = nullptr;
   CK(vt_wrap(vt_gemm_launch(q, c.s), what));
+  const bool hn = hn_w0 && (p.N % 64) == 0;
+  if (hn && hn_done) *hn_done = true;
   return vt_wrap(vt_k_slab_reduce((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, p.act, p.colscale, p.residual, p.ldr, p.C, p.c_dtype,
-                                  p.ldc, c.s), what);
+                                  p.ldc, hn ? hn_w0 : nullptr, hn ? hn_w1 : nullptr, hn_c0, hn_c1, 1e-6f, c.h->d.rms_mode, c.s), what);
 }
 
 // adaptor MLP: Linear (gelu_tanh Linear)*  — final layer writes `dst` (ld = D) with optional per-row-in-sample residual (pos embed)
@@ -273,8 +279,10 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     // --- self attention
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
-      const bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
-      CK(rgemm(c, p, "rdt qkv"));
+      bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
+      bool folded = false;
+      CK(rgemm(c, p, "rdt qkv", fused ? nullptr : b.qn, D, b.kn, 2 * D, &folded));
+      fused = fused || folded;
       if (!fused) {
         CK(vt_k_headnorm(c.ws + c.w.qkv, d.adt, 3 * D, d.heads, M, b.qn, 1e-6f, d.rms_mode, c.s));
         CK(vt_k_headnorm(c.ws + c.w.qkv + (size_t)D * a, d.adt, 3 * D, d.heads, M, b.kn, 1e-6f, d.rms_mode, c.s));
@@ -286,8 +294,10 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     // --- cross attention against the cached condition K/V
     CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
-      const bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
-      CK(rgemm(c, p, "rdt cross q"));
+      bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
+      bool folded = false;
+      CK(rgemm(c, p, "rdt cross q", fused ? nullptr : b.cqn, D, nullptr, D, &folded));
+      fused = fused || folded;
       if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
     CK(cross_attn(c, l, lang_mask, N));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
