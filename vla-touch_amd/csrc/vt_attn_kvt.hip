@@ -28,12 +28,20 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   const int nw = blockDim.x >> 6;
   const int g = lane >> 4, l15 = lane & 15;
   const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
+  // parts > 1 (small batches, a single query block): blockIdx.x is the PART of the sample's key tiles this block covers; the
+  // un-normalised partial (m, l, o) goes to `part_ws` and attn_combine_kernel merges the parts (flash-decoding)
+  const int part = p.parts > 1 ? blockIdx.x : 0;
+  const int q = (p.parts > 1 ? 0 : blockIdx.x * (nw * 16)) + wave * 16 + l15;
   const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
   const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + (long)h * p.T * 8192;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
   const int row0 = b * p.Nk, row1 = row0 + p.Nk;             // this sample's rows of the stream
-  const int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
+  int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
+  if (p.parts > 1) {
+    const int nt = t_last - t_first + 1, per = (nt + p.parts - 1) / p.parts;
+    t_first += part * per;
+    t_last = min(t_last, t_first + per - 1);
+  }
 
   Frag<bf16_t> qf[2];
 #pragma unroll
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   float m_run = -INFINITY, l_run = 0.f;
   const float cscale = p.scale * 1.4426950408889634f;
 
-  stage(0, t_first);
+  if (t_first <= t_last) stage(0, t_first);
   __syncthreads();
   for (int tile = t_first; tile <= t_last; ++tile) {
     const int cur = (tile - t_first) & 1;
@@ -154,6 +162,15 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
+  if (p.parts > 1) {        // partial: [b][h][part][row (16*nw)][66] floats = o[64] | m | l   (m in score units, pre-scale)
+    float* W = p.part_ws + ((((long)b * p.H + h) * p.parts + part) * (nw * 16) + wave * 16 + l15) * 66;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[dt * 16 + g * 4 + r] = o[dt][r];
+    if (g == 0) { W[64] = m_run; W[65] = l; }
+    return;
+  }
   const float inv = 1.0f / l;
   if (q < p.Nq) {
     bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
@@ -164,6 +181,32 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
       t.y = pk_bf16(o[dt][2] * inv, o[dt][3] * inv);
       *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = t;
     }
+  }
+}
+
+// merge the key-range parts of a (batch, head): O = sum_p e^{(m_p - m) c} o_p / sum_p e^{(m_p - m) c} l_p, c = scale*log2(e) (exp2 domain, as above)
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_ws, bf16_t* __restrict__ O, long o_bs, long o_rs, int H, int Nq, int rows_pad,
+                                                          int parts, float cscale) {
+  const int b = blockIdx.z, h = blockIdx.y;
+  for (int e = threadIdx.x; e < Nq * 16; e += blockDim.x) {          // (row, group of 4 d)
+    const int row = e >> 4, d4 = (e & 15) * 4;
+    const float* W = part_ws + ((((long)b * H + h) * parts) * rows_pad + row) * 66;
+    float m = -INFINITY;
+    for (int pi = 0; pi < parts; ++pi) m = fmaxf(m, W[(long)pi * rows_pad * 66 + 64]);
+    float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int pi = 0; pi < parts; ++pi) {
+      const float* Wp = W + (long)pi * rows_pad * 66;
+      const float mp = Wp[64];
+      const float f = (mp == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mp - m) * cscale);
+      l += f * Wp[65];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += f * Wp[d4 + r];
+    }
+    const float inv = 1.0f / l;
+    uint2 t;
+    t.x = pk_bf16(acc[0] * inv, acc[1] * inv);
+    t.y = pk_bf16(acc[2] * inv, acc[3] * inv);
+    *reinterpret_cast<uint2*>(O + (long)b * o_bs + (long)row * o_rs + h * 64 + d4) = t;
   }
 }
 
@@ -212,7 +255,15 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
     const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
     if (padded < best) { best = padded; nw = w; }
   }
-  dim3 grid((p.Nq + nw * 16 - 1) / (nw * 16), p.H, p.B);
+  const int qblocks = (p.Nq + nw * 16 - 1) / (nw * 16);
+  if (p.parts > 1) {
+    if (qblocks != 1 || !p.part_ws) return VT_ERR_ARG;
+    hipLaunchKernelGGL(attn_kvt_kernel, dim3(p.parts, p.H, p.B), dim3(64 * nw), 0, s, p);
+    hipLaunchKernelGGL(attn_combine_kernel, dim3(1, p.H, p.B), dim3(256), 0, s, p.part_ws, (bf16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
+                       p.scale * 1.4426950408889634f);
+    return vt_check_launch();
+  }
+  dim3 grid(qblocks, p.H, p.B);
   hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p);
   return vt_check_launch();
 }

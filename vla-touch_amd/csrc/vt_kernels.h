@@ -38,7 +38,11 @@ struct VtAttnKvtParams {
   const uint8_t* kmask;       // [B][Nk] or null
   int B, H, Nq, Nk, T;        // Nk keys per sample; T = ceil(B*Nk / 64) tiles per head
   float scale;
+  int parts;                  // > 1: split every sample's key tiles over `parts` blocks (needs Nq <= 16*NW and part_ws), merged by a 2nd kernel
+  float* part_ws;             // [B][H][parts][16*NW rows][66] floats
 };
+// bytes of part_ws for vt_attn_kvt_launch with `parts` parts
+inline size_t vt_attn_kvt_part_bytes(int B, int H, int Nq, int parts) { return parts > 1 ? (size_t)B * H * parts * ((Nq + 15) / 16 * 16 + 16) * 66 * 4 : 0; }
 // position of key kk (0..63) inside a Vt tile row: within each 32-key half the keys are stored in the k order of the
 // P fragment (k index g*8 + j <-> key (j>>2)*16 + g*4 + (j&3)), so an A fragment of Vt is one 16-byte chunk.  Aligned pairs
 // and aligned groups of 4 keys stay contiguous.

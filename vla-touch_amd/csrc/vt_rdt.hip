@@ -100,6 +100,7 @@ struct RWs {
       out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, total;
   size_t kv_lang_blk, kv_img_blk;   // bytes per block
   size_t slab_bytes;                // split-K scratch of the small-batch Linears (0 when M is large enough without it)
+  size_t attn_part; int attn_parts; // key-range parts of the cached cross-attention at small batch (1 = off)
 };
 RWs rcarve(const vt_rdt_s* h, int B, int L) {
   const vt_rdt_desc& d = h->d;
@@ -128,6 +129,10 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.noisy = take((size_t)B * d.horizon * d.out_dim * 4); w.noisy_a = take((size_t)B * d.horizon * d.out_dim * a);
   w.slab_bytes = M <= 512 ? (size_t)RDT_MAX_SPLITK * M * 3 * D * 4 : 0;
   w.slab = take(w.slab_bytes);
+  // cached cross-attention: B*H blocks stream a sample's whole key range each; below ~512 blocks split the range (flash-decoding)
+  w.attn_parts = 1;
+  { const int bh = B * d.heads; if (bh < 512 && N <= 128) { w.attn_parts = 512 / bh; if (w.attn_parts > 16) w.attn_parts = 16; if (w.attn_parts < 1) w.attn_parts = 1; } }
+  w.attn_part = take(vt_attn_kvt_part_bytes(B, d.heads, N, w.attn_parts));
   w.total = o;
   return w;
 }
@@ -264,6 +269,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
     p.q_bs = (long)N * D; p.q_rs = D; p.o_bs = (long)N * D; p.o_rs = D;
     p.kmask = lang ? lang_mask : nullptr;
     p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(c.B * Lc) / 64; p.scale = 0.125f;
+    if (c.w.attn_parts > 1 && Lc >= 64 * 2 * c.w.attn_parts) { p.parts = c.w.attn_parts; p.part_ws = (float*)(c.ws + c.w.attn_part); }
     return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
   }
   return attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att);
