@@ -13,6 +13,8 @@ Pinning status:
   * rdt (RDT.forward)                                              — PINNED against the imported
     reference `models/rdt/model.py` run with a restated timm shim (timm is absent; the shim is
     test-side only and is itself unpinned third-party behaviour).
+  * siglip (SigLIP image-token tower)                  — PINNED against the reference's SiglipVisionTower wrapper
+    around HF SiglipVisionModel run here (tools/make_golden_siglip.py -> g11; tests/test_siglip.py).
   * dpm_solver (diffusers DPMSolverMultistepScheduler, absent, not pinned by the reference)
                                                                     — PARITY UNPINNED: restated from
     the published DPM-Solver++(2M) algorithm; golden G9 is produced by this restatement.
