@@ -59,6 +59,9 @@ int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, c
 int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode, hipStream_t s);
 int vt_k_groupnorm(const VtGnParams& p, hipStream_t s);
 // out = residual + colscale * act(sum of S fp32 split-K slabs [S][M][N] + bias); residual has the output dtype
+// x += sum of slabs + bias (fp32, in place), xn = rownorm(x) * w (+ b): a residual Linear and the norm that follows it (N <= 2048)
+int vt_k_slab_reduce_norm(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, float* x, long ldx, const float* w,
+                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s);
 // optional per-head (64 columns) RMSNorm after the bias: hn_w0 for columns [0, hn_c0), hn_w1 for [hn_c0, hn_c1) (then no act / residual use)
 int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
                      const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,

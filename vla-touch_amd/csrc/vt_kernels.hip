@@ -264,6 +264,79 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   }
 }
 
+// Residual Linear + the norm that follows it, for the split-K path: x[m, :] += sum_s slab[s][m, :] + bias (fp32 stream, in place) and
+// xn[m, :] = norm(x[m, :]) * w (+ b) in the activation dtype — one block per row, so the next Linear needs no separate norm launch.
+template <typename TN, int NV>
+__global__ __launch_bounds__(256) void slab_reduce_norm_kernel(const float* __restrict__ slabs, int S, long slab_stride, int N, const float* __restrict__ bias,
+                                                               float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b,
+                                                               float eps, int mode, TN* __restrict__ xn, long ldxn) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
+  const int nv = N >> 2;
+  float4 v[NV];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = tid + 256 * i;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < nv) {
+      float4 acc = *reinterpret_cast<const float4*>(x + (long)m * ldx + c4 * 4);
+      if (bias) { const float4 bb = *reinterpret_cast<const float4*>(bias + c4 * 4); acc.x += bb.x; acc.y += bb.y; acc.z += bb.z; acc.w += bb.w; }
+      for (int k0 = 0; k0 < S; k0 += 4) {          // 4 independent loads in flight
+        float4 t[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          t[u] = k0 + u < S ? *reinterpret_cast<const float4*>(slabs + (long)(k0 + u) * slab_stride + (long)m * N + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { acc.x += t[u].x; acc.y += t[u].y; acc.z += t[u].z; acc.w += t[u].w; }
+      }
+      *reinterpret_cast<float4*>(x + (long)m * ldx + c4 * 4) = acc;
+      v[i] = acc;
+      s += (acc.x + acc.y) + (acc.z + acc.w);
+      q += (acc.x * acc.x + acc.y * acc.y) + (acc.z * acc.z + acc.w * acc.w);
+    }
+  }
+  auto block_sum = [&](float t) {
+    t = wave_sum(t);
+    __syncthreads();
+    if (lane == 0) red[wv] = t;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float mean = 0.f, var;
+  if (mode == VT_NORM_RMS_MEANSQ) {
+    var = block_sum(q) / (float)N;
+  } else {
+    mean = block_sum(s) / (float)N;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (tid + 256 * i < nv) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        d2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    d2 = block_sum(d2);
+    var = (mode == VT_NORM_RMS_VAR) ? d2 / (float)(N - 1) : d2 / (float)N;
+    if (mode == VT_NORM_RMS_VAR) mean = 0.f;
+  }
+  const float rstd = rsqrtf(var + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = tid + 256 * i;
+    if (c4 < nv) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c4 * 4);
+      float o[4] = {(v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y, (v[i].z - mean) * rstd * ww.z, (v[i].w - mean) * rstd * ww.w};
+      if (b) { const float4 bb = *reinterpret_cast<const float4*>(b + c4 * 4); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+      TN* yr = xn + (long)m * ldxn;
+      if constexpr (sizeof(TN) == 4) *reinterpret_cast<float4*>(yr + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      else {
+        TN t[4] = {Elem<TN>::from_f(o[0]), Elem<TN>::from_f(o[1]), Elem<TN>::from_f(o[2]), Elem<TN>::from_f(o[3])};
+        *reinterpret_cast<uint2*>(yr + c4 * 4) = *reinterpret_cast<const uint2*>(t);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ small element-wise kernels
 template <typename TO>
 __global__ void sinusoid_kernel(const float* __restrict__ t, float t_host, TO* __restrict__ out, int B, int dim, int nets, long net_stride, int cos_first, float denom_minus) {
@@ -477,6 +550,14 @@ int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, 
   const long n = (long)M * (N >> 2);
   DISPATCH_T(odt, TO, hipLaunchKernelGGL((slab_reduce_kernel<TO>), g1(n), dim3(256), 0, s, slabs, S, slab_stride, M, N, bias, act, colscale,
                                          (const TO*)residual, ldr, (TO*)out, ldo, hn_w0, hn_w1, hn_c0, hn_c1, hn_eps, hn_mode))
+  return vt_check_launch();
+}
+
+int vt_k_slab_reduce_norm(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, float* x, long ldx, const float* w,
+                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s) {
+  if (S < 1 || (N & 3) || N > 2048 || M <= 0 || (ldx & 3) || (ldxn & 3)) return VT_ERR_ARG;
+  DISPATCH_T(xn_dt, TN, hipLaunchKernelGGL((slab_reduce_norm_kernel<TN, 2>), dim3(M), dim3(256), 0, s, slabs, S, slab_stride, N, bias, x, ldx, w, b, eps,
+                                           mode, (TN*)xn, ldxn))
   return vt_check_launch();
 }
 

@@ -151,9 +151,12 @@ bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1
 // slabs and a second tiny kernel sums them and applies the Linear's epilogue.
 // hn_*: head norm to apply when the GEMM did NOT fuse it (p.hn_w0 unset): folded into the slab reduction on the split path, else
 // the caller's vt_k_headnorm kernels run (returns *hn_done = false).
+// next_norm / xn_done: for a residual Linear into the fp32 stream (C == residual == x, full row width), the RMSNorm that follows it
+// is computed by the slab reduction too (*xn_done = true: c.w.xn holds norm(x) * next_norm).
 int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullptr, int hn_c0 = 0, const float* hn_w1 = nullptr, int hn_c1 = 0,
-          bool* hn_done = nullptr) {
+          bool* hn_done = nullptr, const float* next_norm = nullptr, bool* xn_done = nullptr) {
   if (hn_done) *hn_done = false;
+  if (xn_done) *xn_done = false;
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int nk = p.K / 64;
   int S = (int)(512 / (tiles64 > 0 ? tiles64 : 1));
@@ -166,6 +169,12 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
   q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
   q.bias = nullptr; q.act = VT_ACT_NONE; q.colscale = nullptr; q.residual = nullptr;
   CK(vt_wrap(vt_gemm_launch(q, c.s), what));
+  if (next_norm && xn_done && p.residual == p.C && p.c_dtype == VT_F32 && p.N == c.h->d.hidden && p.N <= 2048 && p.act == VT_ACT_NONE &&
+      !p.colscale && p.ldc == p.N && p.ldr == p.N) {
+    *xn_done = true;
+    return vt_wrap(vt_k_slab_reduce_norm((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, (float*)p.C, p.ldc, next_norm, nullptr, 1e-6f,
+                                         c.h->d.rms_mode, c.ws + c.w.xn, c.h->d.adt, p.N, c.s), what);
+  }
   const bool hn = hn_w0 && (p.N % 64) == 0;
   if (hn && hn_done) *hn_done = true;
   return vt_wrap(vt_k_slab_reduce((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, p.act, p.colscale, p.residual, p.ldr, p.C, p.c_dtype,
@@ -280,10 +289,13 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
   const vt_rdt_desc& d = c.h->d;
   const int D = d.hidden, N = d.horizon + 3, M = c.B * N, a = c.a;
   float* x = (float*)(c.ws + c.w.x);
+  bool xn_ready = false;              // c.w.xn already holds the next norm of x (fused into the previous residual Linear's slab reduction)
   for (int l = 0; l < d.depth; ++l) {
     const Blk& b = c.h->blk[l];
+    const float* norm_after = l + 1 < d.depth ? c.h->blk[l + 1].norm1 : c.h->normf;     // the norm that follows this block's fc2
     // --- self attention
-    CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
       bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
       bool folded = false;
@@ -296,9 +308,10 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     CK(attn(c, c.ws + c.w.qkv, 3 * D, c.ws + c.w.qkv + (size_t)D * a, c.ws + c.w.qkv + (size_t)2 * D * a, 3 * D, N, N, nullptr, c.ws + c.w.att));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(rgemm(c, p, "rdt proj")); }
+      CK(rgemm(c, p, "rdt proj", nullptr, 0, nullptr, 0, nullptr, b.norm2, &xn_ready)); }
     // --- cross attention against the cached condition K/V
-    CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
       bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       bool folded = false;
@@ -308,16 +321,17 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     CK(cross_attn(c, l, lang_mask, N));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(rgemm(c, p, "rdt cross proj")); }
+      CK(rgemm(c, p, "rdt cross proj", nullptr, 0, nullptr, 0, nullptr, b.norm3, &xn_ready)); }
     // --- FFN (hidden = D, tanh-GELU)
-    CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+    xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
       CK(rgemm(c, p, "rdt fc1")); }
     { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
       p.residual = x; p.ldr = D;
-      CK(rgemm(c, p, "rdt fc2")); }
+      CK(rgemm(c, p, "rdt fc2", nullptr, 0, nullptr, 0, nullptr, norm_after, &xn_ready)); }
   }
-  CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
+  if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
   { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
     CK(rgemm(c, p, "rdt final fc1")); }
   { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE);
