@@ -224,7 +224,7 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   int nw = 4, best = 1 << 30;
   for (int w = 4; w <= 8; ++w) {                      // fewest padded query rows; ties -> fewer waves
     const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
-    if (padded < best) { best = padded; nw = w; }
+    if (padded < best || (padded == best && p.Nk >= 512 && w == 8)) { best = padded; nw = w; }   // long key sequences: K/V staged once per 128 rows (+3 % on SigLIP)
   }
   const int rows = nw * 16;
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
