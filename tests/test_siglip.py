@@ -138,3 +138,41 @@ def test_wrapper_step_end_to_end():
                                   img_tokens=img_tokens, state_tokens=st[:, -1:], action_mask=mask.unsqueeze(1),
                                   ctrl_freqs=torch.tensor([10], device="cuda:0"))
     assert torch.equal(traj, m._unformat_action_to_joint(ref).float())
+
+
+@pytest.mark.gpu
+def test_batched_episode_labelling_equals_per_timestep_steps():
+    """vlatouch.label.label_episode (frames encoded once, chunks generated in batches) == the reference's loop of
+    policy.step(...) over the 2-deep observation window (create_controller_dataset_episode.py:186-205), timestep by timestep."""
+    from models.multimodal_encoder.siglip_encoder import SiglipVisionTower
+    from scripts.franka_model_eef import RoboticDiffusionTransformerModel
+    from vlatouch.label import label_episode
+    c = synth.SIGLIP_CONFIGS["tiny"]
+    cfg = dict(hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+               image_size=c["image_size"], patch_size=14)
+    tower = SiglipVisionTower("synthetic", None, device="cuda:0", precision="fp32", state_dict=cases.siglip_sd("tiny"), config=cfg)
+    m = RoboticDiffusionTransformerModel(ARGS, device="cuda:0", dtype=torch.float32, control_frequency=10, vision_model=tower)
+    g = np.random.default_rng(21)
+    N = 7
+    cam1 = (g.random((N, 56, 56, 3)) * 255).astype(np.uint8)
+    cam2 = (g.random((N, 56, 56, 3)) * 255).astype(np.uint8)
+    qpos = g.standard_normal((N, 10)).astype(np.float32)
+    qpos[:, 9] = g.uniform(0, 255, N)
+    text = torch.from_numpy(g.standard_normal((1, 12, 96)).astype(np.float32))
+    noise = torch.from_numpy(g.standard_normal((N, 8, 128)).astype(np.float32))
+    got = label_episode(m, cam1, cam2, qpos, text, batch=3, noise=noise, encode_batch=4)
+    assert got.shape == (N, 8, 10) and got.dtype == np.float32
+    # the reference's loop, one timestep at a time through step()'s own code path (noise injected through the generator it draws from)
+    from PIL import Image
+    for t in range(N):
+        imgs = [Image.fromarray(cam1[t - 1]) if t > 0 else None, Image.fromarray(cam2[t - 1]) if t > 0 else None, None,
+                Image.fromarray(cam1[t]), Image.fromarray(cam2[t]), None]
+        px = m.preprocess_images(imgs).to("cuda:0")
+        tokens = tower(px).reshape(1, -1, 576)
+        st, mask = m._format_joint_to_state(torch.from_numpy(qpos[t:t + 1]).cuda().unsqueeze(0))
+        ref = m.policy.predict_action(lang_tokens=text.cuda(), lang_attn_mask=torch.ones(1, 12, dtype=torch.bool, device="cuda:0"),
+                                      img_tokens=tokens, state_tokens=st[:, -1:], action_mask=mask.unsqueeze(1),
+                                      ctrl_freqs=torch.tensor([10.0], device="cuda:0"), x_init=noise[t:t + 1].cuda())
+        ref = m._unformat_action_to_joint(ref).float().cpu().numpy()[0]
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert float(np.abs(got[t] - ref).max()) < 2e-4 * scale, t
