@@ -296,8 +296,40 @@ def main():
                 "traffic": (round(pmc[name.split(" ")[0]]["per_launch_bytes"] / 1e9, 4) if name.split(" ")[0] in pmc else None),
                 "traffic_unit": "GB per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
                 "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4)}
+    # on-box measured peaks (report fractions of the nominal AND of a measured peak): a large square bf16 GEMM on the
+    # same kernel family and a device-to-device copy (read + write bytes)
+    onbox = None
+    if rank == 0:
+        from vlatouch import ops as _ops
+        with torch.cuda.stream(stream):
+            a8 = torch.randn(8192, 8192, device=dev).to(torch.bfloat16)
+            w8 = (torch.randn(8192, 8192, device=dev) * 0.01).to(torch.bfloat16)
+            o8 = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+            src = torch.empty(1 << 28, device=dev, dtype=torch.float32)            # 1 GiB
+            dst = torch.empty_like(src)
+            for _ in range(2):
+                _ops.gemm(a8, w8, out=o8, out_dtype=torch.bfloat16)
+                dst.copy_(src)
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(stream)
+            for _ in range(5):
+                _ops.gemm(a8, w8, out=o8, out_dtype=torch.bfloat16)
+            e[1].record(stream)
+            for _ in range(5):
+                dst.copy_(src)
+            e[2].record(stream)
+            stream.synchronize()
+            onbox = {"bf16_gemm_8192_tflops": round(5 * 2 * 8192 ** 3 / (e[0].elapsed_time(e[1]) * 1e-3) / 1e12, 1),
+                     "d2d_copy_GBs": round(5 * 2 * src.numel() * 4 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e9, 1)}
+            del a8, w8, o8, src, dst
+
     r_pp = roof(2, "gemm_pp256_kernel (256x256x64 ping-pong tile, 16-bit MFMA: condition K/V projections, image adaptor, DINOv2 Linears)")
     r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
+    if onbox is not None:
+        res["onbox_peaks"] = onbox
+        for r in (r_pp, r_gl):
+            if r is not None:
+                r["frac_of_measured_gemm_peak"] = round(r["achieved"] / onbox["bf16_gemm_8192_tflops"], 4)
     if r_pp is not None:
         res["roofline"] = r_pp
         if r_gl is not None:
