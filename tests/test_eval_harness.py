@@ -76,3 +76,30 @@ def test_evaluator_metrics_golden(prec):
     assert len(r2["test_errors"]) == 2 and r2["chosen"] == ev.evaluate(ctrl, eps, num_samples=2, horizon=16, seed=3)["chosen"]
     pred, expert, vla = ev.refine_batch(ctrl, next(ev.batches(eps, 32, 2, 16)), 2, noises[0])
     assert float((pred.cpu() - torch.from_numpy(g["pred_b0"])).abs().max()) < (2e-4 if prec == "fp32" else 3e-2)
+
+
+@pytest.mark.gpu
+def test_refine_episode_is_the_batch_path_over_one_episode():
+    """vlatouch.eval.refine_episode (SURVEY §8a-10's entry point): every window of one episode, in loader order, equals the
+    batch-by-batch refine_batch calls, and its metrics are the evaluator's formulas over the whole episode."""
+    from residual_controller.bridge_controller import DiffusionController
+    from vlatouch import eval as ev, synth
+    eps = [ev.load_episode(p) for p in EP]
+    ctrl = cases.build_controller(DiffusionController, precision="fp32")
+    ctrl.stats = {k: torch.as_tensor(v, dtype=torch.float32).cuda() for k, v in ev.normalization_stats(eps).items()}
+    ep = eps[0]
+    nwin = len(ev.episode_windows(ep, 2, 16, 1))
+    z = cases.T(synth.inputs_rng(77).standard_normal((10, nwin, 16, 10), dtype=np.float32)).cuda()
+    pred, met = ev.refine_episode(ctrl, ep, batch_size=8, horizon=16, noise=z)
+    assert pred.shape == (nwin, 16, 10)
+    parts, exps, vlas, done = [], [], [], 0
+    for b in ev.batches([ep], 8, 2, 16):
+        n = b["states"].shape[0]
+        p, e, v = ev.refine_batch(ctrl, b, 2, z[:, done:done + n].contiguous())
+        parts.append(p); exps.append(e); vlas.append(v)
+        done += n
+    assert done == nwin and torch.equal(pred, torch.cat(parts))
+    err = torch.mean((torch.cat(parts) - torch.cat(exps)) ** 2).item()
+    verr = torch.mean((torch.cat(vlas) - torch.cat(exps)) ** 2).item()
+    assert abs(met["error"] - err) < 1e-9 and abs(met["vla_error"] - verr) < 1e-9
+    assert abs(met["improvement"] - (1 - err / verr) * 100) < 1e-6

@@ -168,3 +168,25 @@ def evaluate(controller, episodes: Sequence[Dict[str, np.ndarray]], num_samples:
     avg, avg_vla = sum(errs) / len(errs), sum(vla_errs) / len(vla_errs)
     return {"avg_error": avg, "avg_vla_error": avg_vla, "improvement": (1.0 - avg / avg_vla) * 100 if avg_vla > 0 else 0,
             "test_errors": errs, "test_vla_errors": vla_errs, "chosen": list(chosen)}
+
+
+def refine_episode(controller, episode: Dict[str, np.ndarray], batch_size: int = 32, horizon: int = 32, stride: int = 1,
+                   noise: Optional[torch.Tensor] = None):
+    """All windows of ONE episode through `predict`, in validation-loader order: returns the refined chunks
+    [n_windows, horizon, 10], and the evaluator's three metrics over the whole episode — MSE(pred, expert), MSE(vla, expert),
+    improvement %.  `noise` (optional) is [10, n_windows, horizon, 10], sliced per batch."""
+    cf = controller.model_args.get("context_frames", 2) if controller.model_args else 2
+    preds, experts, vlas = [], [], []
+    done = 0
+    for b in batches([episode], batch_size, cf, horizon, stride):
+        n = b["states"].shape[0]
+        z = None if noise is None else noise[:, done:done + n].contiguous()
+        p, e, v = refine_batch(controller, b, cf, z)
+        preds.append(p); experts.append(e); vlas.append(v)
+        done += n
+    if not preds:
+        return torch.empty(0, horizon, 10), {"error": float("nan"), "vla_error": float("nan"), "improvement": 0.0}
+    pred, expert, vla = torch.cat(preds), torch.cat(experts), torch.cat(vlas)
+    err = torch.mean((pred - expert) ** 2).item()
+    verr = torch.mean((vla - expert) ** 2).item()
+    return pred, {"error": err, "vla_error": verr, "improvement": (1.0 - err / verr) * 100 if verr > 0 else 0.0}
