@@ -93,13 +93,13 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from tests import cases
     from vlatouch import _lib as L
+    from vlatouch import synth
     from residual_controller.bridge_controller import DiffusionController
 
     # ---- frozen weights: rank 0 generates the deterministic synthetic set, the others receive it over RCCL
     t0 = time.time()
-    ctrl = cases.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats_kind="unit")
+    ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats())
     if world > 1:
         from vlatouch.dist import broadcast_controller_weights
         nbytes = broadcast_controller_weights(ctrl, src=0)
@@ -115,7 +115,6 @@ def main():
                  state_token_dim=128, max_lang_cond_len=1024, img_cond_len=4374)
     if args.workload in ("full", "rdt"):
         from models.rdt_runner import RDTRunner
-        from vlatouch import synth
         rdt_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
         cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
                "state_adaptor": "mlp3x_gelu",
@@ -135,18 +134,19 @@ def main():
         rin = dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
                    state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
     lstm = lstm_in = None
+    dino_c = synth.DINOV2_CONFIGS[args.dino]
+    dino_sd = synth.torch_state_dict(synth.dinov2_shapes(dino_c["hidden"], dino_c["layers"]), prefix=f"dinov2-{args.dino}.")
     if args.workload == "lstm":         # the alternative residual head: obs encoding + T sequential LSTM ticks per chunk
         from residual_controller.lstm_step_controller import TactileLSTMController
         lstm = TactileLSTMController(device=dev, precision=args.precision, image_model_path=f"facebook/dinov2-{args.dino}",
-                                     image_state_dict=cases.dino_sd(args.dino))
-        for name, sd in cases.lstm_mods(768 if args.dino == "base" else 384).items():
-            getattr(lstm, name).load_state_dict(sd)
+                                     image_state_dict=dino_sd)
+        for name, shp in synth.lstm_controller_shapes(dino_c["hidden"]).items():
+            getattr(lstm, name).load_state_dict(synth.torch_state_dict(shp, prefix=f"lstm_ctrl.{name}."))
         lstm.to(dev)
-        lstm.stats = {k: v.to(dev) for k, v in cases.stats("unit").items()}
+        lstm.stats = {k: v.to(dev) for k, v in synth.unit_stats().items()}
         lstm_in = dict(forces=torch.randn(B, T, 3, device=dev))
     sig = sig_px = None
     if args.workload == "siglip":       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
-        from vlatouch import synth
         from vlatouch.engine import SiglipEngine
         c = synth.SIGLIP_CONFIGS["so400m"]
         wdt = torch.float32
@@ -347,8 +347,8 @@ def main():
         CB = min(B, args.cpu_batch)
         cpu = {k: v[:CB].cpu() for k, v in inp.items()}
         z = torch.randn(10, CB, T, 10)
-        sds = (cases.dino_sd(args.dino), cases.state_encoder_sd(2 * (768 if args.dino == "base" else 384) + 13), cases.si_net_sd("ema"),
-               cases.stats("unit"))
+        sds = (dino_sd, synth.torch_state_dict(synth.state_encoder_shapes(2 * dino_c["hidden"] + 13), prefix="state_encoder."),
+               synth.torch_state_dict(synth.si_net_shapes(10, 256), prefix="si.", salt="ema"), synth.unit_stats())
         heads = 12 if args.dino == "base" else 6
         f = lambda: oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"], cpu["vla"], cpu["cam1"], cpu["cam2"], cpu["forces"], z)
         t1 = time.perf_counter(); ref = f(); first = time.perf_counter() - t1     # also the parity check of the benchmarked config
@@ -365,15 +365,26 @@ def main():
             from oracle import rdt as orr
             sd_cpu = {k: v.float().cpu() for k, v in rdt.state_dict().items()}
             c1 = {k: (v[:1].float().cpu() if v.dtype != torch.bool else v[:1].cpu()) for k, v in rin.items()}
-            x0 = torch.randn(1, 64, 128)
+            # the SAME start noise for the GPU batch and the oracle's episode 0: the timed oracle run doubles as the parity check of
+            # the benchmarked configuration (B = 32 rows through the large-batch kernels; oracle = fp32 math on the bf16-rounded weights)
+            gx = torch.Generator(device=dev).manual_seed(99)
+            x_init = torch.randn(B, 64, 128, generator=gx, device=dev, dtype=torch.float32).to(rdt_dtype)
+            with torch.cuda.stream(stream):
+                gpu_chunk = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init)
+                stream.synchronize()
             t1 = time.perf_counter()
-            orr.predict_action(sd_cpu, c1["lang"], c1["mask"], c1["img"], c1["state"], c1["amask"], c1["freq"], x0, heads=32, horizon=64,
-                               num_inference_steps=args.rdt_steps)
+            ref_chunk = orr.predict_action(sd_cpu, c1["lang"], c1["mask"], c1["img"], c1["state"], c1["amask"], c1["freq"], x_init[:1].float().cpu(),
+                                           heads=32, horizon=64, num_inference_steps=args.rdt_steps, rms_mode=rdt.rms_mode)
             t_rdt = time.perf_counter() - t1
+            rdt_diff = float((gpu_chunk[0].float().cpu() - ref_chunk[0]).abs().max())
+            rdt_scale = float(ref_chunk.abs().max())
             sample += f"; RDT-1B: 1 oracle predict_action on 1 episode ({args.rdt_steps} steps, fp32)"
         res["cpu_baseline"] = {"value": round(1.0 / (t_pi + t_rdt), 3), "unit": "chunks/s", "cores": cores, "kind": "port", "sample": sample,
                                "pi_s_per_chunk": round(t_pi, 4), "rdt_s_per_chunk": round(t_rdt, 3),
                                "max_abs_diff_vs_gpu_pi": float((got - ref).abs().max())}
+        if args.workload == "full":
+            res["cpu_baseline"].update({"max_abs_diff_vs_gpu_rdt": rdt_diff, "rdt_output_scale": rdt_scale,
+                                        "rdt_parity_note": "GPU batch row 0 (bf16, B=%d) vs oracle fp32 on the same bf16-rounded weights / inputs / start noise" % B})
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

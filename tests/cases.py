@@ -92,30 +92,12 @@ def stats(kind: str = "nontrivial") -> Dict[str, torch.Tensor]:
     return {k: T(v) for k, v in d.items()}
 
 
-MODEL_ARGS = {
-    'interpolant_type': 'linear', 'gamma_type': '2^0.5*t(t-1)', 'epsilon_type': '1-t', 'prior_policy': 'vla',
-    'beta_max': 0.03, 'sde_type': 'vs', 'action_dim': 10, 'obs_dim': 256, 'obs_horizon': 1,
-    'net_type': 'unet1D_si', 'pretrain': False, 'context_frames': 2, 'horizon': 16,
-}
+MODEL_ARGS = synth.MODEL_ARGS
 
 
 def build_controller(cls, precision: str, device="cuda:0", size: str = "small", stats_kind: str = "nontrivial", **kw):
-    """A DiffusionController (the product's mirror class) filled with the synthetic weights the goldens were made
-    with: raw `net` params = salt "", EMA shadow params = salt "ema" (the sampler must use the latter)."""
-    ctrl = cls(state_dim=10, hidden_dim=256, image_model_path=f"facebook/dinov2-{size}", diffusion_steps=10, device=device,
-               model_args=dict(MODEL_ARGS), use_force=True, force_dim=3, precision=precision, image_state_dict=dino_sd(size), **kw)
-    latent = synth.DINOV2_CONFIGS[size]["hidden"]
-    ctrl.state_encoder.load_state_dict(state_encoder_sd(2 * latent + 13))
-    ctrl.force_decoder.load_state_dict(force_decoder_sd())
-    ctrl.diffusion_model.net.load_state_dict(si_net_sd(""))
-    ema = si_net_sd("ema")
-    ctrl.diffusion_model.ema.load_state_dict({"decay": 0.75, "num_updates": 0, "collected_params": None,
-                                              "shadow_params": [ema[k] for k in ctrl.diffusion_model.net.state_dict().keys()]})
-    ctrl.diffusion_model.net.to(device)
-    ctrl.diffusion_model.ema.to(device)
-    ctrl.state_encoder.to(device)
-    ctrl.stats = {k: v.to(device) for k, v in stats(stats_kind).items()}
-    return ctrl
+    """vlatouch.synth.build_controller with this module's normalisation statistics."""
+    return synth.build_controller(cls, precision, device=device, size=size, stats=stats(stats_kind), **kw)
 
 
 # ------------------------------------------------------------------ inputs

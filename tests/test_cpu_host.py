@@ -186,3 +186,23 @@ def test_weight_broadcast_world2_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_rms_mode_is_an_explicit_choice(monkeypatch):
+    """timm's RmsNorm arithmetic is third-party and unpinned (models/rdt/blocks.py:22): argument > config > environment > warned default."""
+    import warnings
+    from models import rdt_runner as rr
+    monkeypatch.delenv("VLATOUCH_TIMM_RMSNORM", raising=False)
+    assert rr.resolve_rms_mode("var", {}) == "var"
+    assert rr.resolve_rms_mode(None, {"rms_norm": "var"}) == "var"
+    assert rr.resolve_rms_mode("meansq", {"rms_norm": "var"}) == "meansq"
+    monkeypatch.setenv("VLATOUCH_TIMM_RMSNORM", "var")
+    assert rr.resolve_rms_mode(None, {}) == "var"
+    monkeypatch.delenv("VLATOUCH_TIMM_RMSNORM")
+    rr._warned_default_rms = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert rr.resolve_rms_mode(None, {}) == "meansq"
+    assert any("timm==1.0.3" in str(x.message) for x in w)
+    with pytest.raises(ValueError):
+        rr.resolve_rms_mode("l2", {})

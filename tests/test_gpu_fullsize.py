@@ -90,3 +90,77 @@ def test_pi_refine_full_batch_split_invariance():
         part = ctrl.predict(state[sl], vla[sl], cam1[sl], cam2[sl], forces[sl], noise=z[:, sl].contiguous())
         e = float((part - full[sl]).abs().max())
         assert e < 5e-3, e          # tile choice depends on M (bf16/fp16 summation grouping); the target on a_hat is 1e-2
+
+
+# ---------------------------------------------------------------- full-size parity against the oracle
+def _oracle_episode(r, d, b, steps):
+    """The oracle's predict_action (fp32 math) on episode b alone, with the runner's bf16-rounded weights, inputs and start noise."""
+    from oracle import rdt as orr
+    torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
+    sd = {k: v.float().cpu() for k, v in r.state_dict().items()}
+    one = lambda t: (t[b:b + 1].float().cpu() if t.dtype != torch.bool else t[b:b + 1].cpu())
+    return orr.predict_action(sd, one(d["lang"]), one(d["mask"]), one(d["img"]), one(d["state"]), one(d["amask"]), one(d["freq"]), one(d["x0"]),
+                              heads=32, horizon=64, num_inference_steps=steps, rms_mode=r.rms_mode)[0]
+
+
+def test_rdt_1b_batch32_rows_vs_oracle(rdt1b):
+    """BASELINE configs[3]'s RDT leg exactly as bench.py times it: B=32 (M = 2144 rows / 139 968 condition rows -> gemm_ppk_kernel,
+    gemm_pp256_kernel<..,1|2> and the un-split attn_kvt_kernel), 5 DPM-Solver++ steps; rows 0 and 31 against the oracle run on those
+    single episodes.  Bar: 1e-2 of the output scale (bf16 storage, 28 blocks x 5 steps; models/rdt_runner.py:122-165,225-250)."""
+    d = rdt_inputs(32, seed=17)
+    rdt1b.num_inference_timesteps = 5
+    full = run(rdt1b, d)
+    assert full.shape == (32, 64, 128) and torch.isfinite(full).all()
+    for b in (0, 31):
+        ref = _oracle_episode(rdt1b, d, b, 5)
+        scale = float(ref.abs().max())
+        e = float((full[b].cpu() - ref).abs().max())
+        print(f"[RDT-1B B=32 row {b}] scale {scale:.3f}  |hip16 - oracle32| {e:.3e}  ({e / scale:.2e} of scale)")
+        assert e <= 1e-2 * max(1.0, scale), (b, e, scale)
+
+
+def test_rdt_1b_50_steps_batch16(rdt1b):
+    """BASELINE configs[2]: RDT-1B, 50 denoise steps, B=16 — determinism, batch invariance and row-0 parity against the oracle."""
+    d = rdt_inputs(16, seed=23)
+    rdt1b.num_inference_timesteps = 50
+    try:
+        full = run(rdt1b, d)
+        assert full.shape == (16, 64, 128) and torch.isfinite(full).all()
+        assert torch.equal(full, run(rdt1b, d))
+        scale = float(full.abs().max())
+        alone = run(rdt1b, d, slice(5, 6))
+        e_inv = float((alone[0] - full[5]).abs().max())
+        print(f"[RDT-1B 50 steps] scale {scale:.3f}  batch-invariance row 5: {e_inv:.3e}")
+        assert e_inv <= 2e-2 * scale, (e_inv, scale)
+        ref = _oracle_episode(rdt1b, d, 0, 50)
+        e = float((full[0].cpu() - ref).abs().max())
+        rs = float(ref.abs().max())
+        print(f"[RDT-1B B=16 50 steps row 0] scale {rs:.3f}  |hip16 - oracle32| {e:.3e}  ({e / rs:.2e} of scale)")
+        assert e <= 1e-2 * max(1.0, rs), (e, rs)
+    finally:
+        rdt1b.num_inference_timesteps = 5
+
+
+def test_rdt_chunk_feeds_pi_refine_vs_oracle():
+    """The chained path of frank_inference_eef.py:495-533 at a size the oracle runs in seconds: RDT chunk -> first T ticks x 10 EEF
+    dims -> DiffusionController.predict, fp32 end to end, against oracle(RDT) -> oracle(predict)."""
+    from oracle import rdt as orr
+    from oracle import controller as oc
+    from tests.test_gpu_rdt import make_runner
+    from residual_controller.bridge_controller import DiffusionController
+    cfg = cases.RDT_TINY
+    r = make_runner(cfg, torch.float32)
+    ri = cases.rdt_inputs(cfg, 2, 12)
+    T = cfg["horizon"]                                              # 8 ticks (divisible by 4 for the U-Net)
+    chunk = r.predict_action(ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"],
+                             x_init=ri["x_init"])
+    inp = cases.predict_inputs(2, T, 224)
+    ctrl = cases.build_controller(DiffusionController, precision="fp32", device=DEV)
+    out = ctrl.predict(inp["state"], chunk[:, :T, :10].float(), inp["cam1"], inp["cam2"], inp["forces"], noise=inp["z"])
+    ref_chunk = orr.predict_action(cases.rdt_sd(cfg), ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"],
+                                   ri["freq"], ri["x_init"], heads=cfg["heads"], horizon=cfg["horizon"], num_inference_steps=5)
+    ref = oc.predict(cases.dino_sd("small"), 6, cases.state_encoder_sd(781), cases.si_net_sd("ema"), cases.stats("nontrivial"),
+                     inp["state"], ref_chunk[:, :T, :10], inp["cam1"], inp["cam2"], inp["forces"], inp["z"])
+    e = float((out.cpu() - ref).abs().max())
+    print(f"[chained RDT -> pi_I fp32] max|a_hat - oracle| = {e:.3e}")
+    assert out.shape == (2, T, 10) and e < 1e-4, e

@@ -202,3 +202,55 @@ def test_rdt_forward_edge_language_lengths(dname, dtype, B, L, valid):
     scale = max(1.0, float(exact.abs().max()))
     e = err(y, exact.numpy())
     assert e < (2e-4 if dname == "f32" else 3e-2) * scale, (dname, B, L, valid, e)
+
+
+@pytest.mark.parametrize("dname,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
+def test_rdt_wide_var_rmsnorm(dname, dtype):
+    """timm==1.0.3 `RmsNorm` (rsqrt(var_unbiased + eps), the upstream-checkpoint setting; models/rdt/blocks.py:22) at D=2048, B=4:
+    row norms, the q/k head norms fused into the large-GEMM epilogues and the cached-condition k_norm all take `var` mode."""
+    from oracle import rdt as orr
+    from models.rdt.model import RDT
+    cfg = cases.RDT_WIDE
+    sd16 = cases.rdt_sd(cfg, dtype)
+    m = RDT(output_dim=cfg["action_dim"], horizon=cfg["horizon"], hidden_size=cfg["hidden"], depth=cfg["depth"], num_heads=cfg["heads"],
+            max_lang_cond_len=cfg["max_lang_cond_len"], img_cond_len=cfg["img_cond_len"], dtype=dtype, rms_mode="var")
+    m.load_state_dict({k[len("model."):]: v for k, v in cases.rdt_sd(cfg, torch.float32).items() if k.startswith("model.")})
+    ri = cases.rdt_inputs(cfg, 4, 20, seed=13, dtype=dtype)
+    y = m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"])
+    f32 = {k: v.float() for k, v in sd16.items()}
+    rf = {k: (v.float() if v.is_floating_point() else v) for k, v in ri.items()}
+    kw = dict(lang_mask=rf["lang_mask"], heads=cfg["heads"], horizon=cfg["horizon"], rms_mode="var")
+    exact = orr.rdt_forward(f32, rf["x"], rf["freq"], rf["t"], rf["lang_c"], rf["img_c"], **kw)
+    other = orr.rdt_forward(f32, rf["x"], rf["freq"], rf["t"], rf["lang_c"], rf["img_c"], **dict(kw, rms_mode="meansq"))
+    scale = float(exact.abs().max())
+    e = err(y, exact.numpy())
+    assert err(other, exact.numpy()) > 10 * e or dname == "bf16"      # the two modes are distinguishable at this size
+    if dname == "f32":
+        assert e < 2e-4 * max(1.0, scale), e
+    else:
+        ref16 = orr.rdt_forward(sd16, ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"], lang_mask=ri["lang_mask"], heads=cfg["heads"],
+                                horizon=cfg["horizon"], rms_mode="var")
+        e_ref = err(ref16.float(), exact.numpy())
+        print(f"[wide var] scale {scale:.2f}: |hip16-exact| {e:.3e}  |ref16-exact| {e_ref:.3e}")
+        assert e <= max(1e-2 * scale, 1.5 * e_ref), (e, e_ref)
+
+
+def test_engine_rejects_wrong_shapes():
+    """The C driver indexes raw pointers with the packed config; the host side must refuse what the reference would refuse."""
+    cfg = cases.RDT_TINY
+    r = make_runner(cfg, torch.float32)
+    ri = cases.rdt_inputs(cfg, 2, 12)
+    a = [ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"]]
+    bad_img = list(a); bad_img[2] = ri["img_tokens"][:, :-1]                 # one image token short
+    bad_mask = list(a); bad_mask[1] = ri["lang_mask"][:, :-1]
+    bad_freq = list(a); bad_freq[5] = ri["freq"][:1]
+    for bad in (bad_img, bad_mask, bad_freq):
+        with pytest.raises(ValueError):
+            r.predict_action(*bad, x_init=ri["x_init"])
+    with pytest.raises(ValueError):
+        r.predict_action(*a, x_init=ri["x_init"][:, :-1])
+    m = make_rdt(cfg, torch.float32)
+    with pytest.raises(ValueError):
+        m(ri["x"][:, :-1], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"])
+    with pytest.raises(ValueError):
+        m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"][:, 1:])

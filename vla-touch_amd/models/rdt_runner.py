@@ -44,6 +44,31 @@ class _Adaptor(ParamModule):
         super().__init__(shapes, device="cpu", seed=seed, materialize=materialize)
 
 
+RMS_MODES = ("meansq", "var")
+_warned_default_rms = False
+
+
+def resolve_rms_mode(explicit: Optional[str], rdt_cfg: dict) -> str:
+    """Which arithmetic timm's `RmsNorm` (models/rdt/blocks.py:22) stands for — third-party, NOT pinned by the reference:
+      "meansq": x * rsqrt(mean(x^2) + eps) * w        timm >= 1.0.9 (and every textbook RMSNorm)
+      "var"   : x * rsqrt(var_unbiased(x) + eps) * w  timm <= 1.0.8 — incl. timm==1.0.3, which upstream RDT-1B pins and
+                                                       whose released checkpoints were therefore trained with
+    Order: the `rms_mode=` constructor argument, `config['rdt']['rms_norm']`, the VLATOUCH_TIMM_RMSNORM environment variable,
+    else "meansq" with a one-time warning (a silent default would hide a mismatch with the deployed timm)."""
+    global _warned_default_rms
+    mode = explicit or rdt_cfg.get('rms_norm') or os.environ.get("VLATOUCH_TIMM_RMSNORM")
+    if mode is None:
+        if not _warned_default_rms:
+            import warnings
+            warnings.warn("RDTRunner: RmsNorm arithmetic not specified (rms_mode= / config['rdt']['rms_norm']); using 'meansq' "
+                          "(timm >= 1.0.9).  Checkpoints trained under upstream RDT-1B's pinned timm==1.0.3 need 'var'.", stacklevel=3)
+            _warned_default_rms = True
+        mode = "meansq"
+    if mode not in RMS_MODES:
+        raise ValueError(f"rms_mode must be one of {RMS_MODES}, got {mode!r}")
+    return mode
+
+
 class RDTRunner:
     def __init__(self, *, action_dim, pred_horizon, config, lang_token_dim, img_token_dim, state_token_dim, max_lang_cond_len,
                  img_cond_len, lang_pos_embed_config=None, img_pos_embed_config=None, dtype=torch.bfloat16, device="cuda",
@@ -52,7 +77,7 @@ class RDTRunner:
         self.config = config
         self.dtype = dtype
         self.device = device
-        self.rms_mode = rms_mode or os.environ.get("VLATOUCH_TIMM_RMSNORM", "meansq")
+        self.rms_mode = resolve_rms_mode(rms_mode, config.get('rdt', {}))
         self._init_weights = init_weights     # False: shapes only, weights arrive via load_state_dict(..., assign=True)
         self.model = RDT(output_dim=action_dim, horizon=pred_horizon, hidden_size=hidden_size, depth=config['rdt']['depth'],
                          num_heads=config['rdt']['num_heads'], max_lang_cond_len=max_lang_cond_len, img_cond_len=img_cond_len,

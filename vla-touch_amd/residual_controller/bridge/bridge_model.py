@@ -107,7 +107,7 @@ class StochasticInterpolants:
             self._sampler = (key, eng)
         return self._sampler[1]
 
-    def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise):
+    def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise, record=True):
         if direction != 'forward':
             raise NotImplementedError("only the forward direction is used by sample() and implemented here")
         if score_weight != 1.0:
@@ -119,23 +119,23 @@ class StochasticInterpolants:
         if noise is None:   # the reference's `self.d * torch.randn_like(current_x)` draws, made up-front
             noise = torch.randn((n_steps,) + tuple(x_initial.shape), dtype=torch.float32, device=dev)
         eng = self._sampler_engine(nets, dev)
-        xT, traj = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=True,
+        xT, traj = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,
                               gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code)
-        return xT, [traj[i] for i in range(traj.shape[0])]
+        return xT, ([traj[i] for i in range(traj.shape[0])] if traj is not None else None)
 
-    def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None):
-        return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise)
+    def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True):
+        return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise, record)
 
-    def sde_bs(self, b_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None):
-        return self._run(("b_net", "s_net"), 1, x_initial, cond, delta_t, score_weight, direction, noise)
+    def sde_bs(self, b_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True):
+        return self._run(("b_net", "s_net"), 1, x_initial, cond, delta_t, score_weight, direction, noise, record)
 
     def sample(self, x_prior, cond, diffuse_step=10, recod_traj=False, noise=None):
         """x_prior (batch, T, dim) normalised prior actions, cond (batch, obs_dim) -> refined normalised actions."""
         with torch.no_grad():
             if self.sde_type == 'vs':
-                x_target, x_target_traj = self.sde_vs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise)
+                x_target, x_target_traj = self.sde_vs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj)
             elif self.sde_type == 'bs':
-                x_target, x_target_traj = self.sde_bs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise)
+                x_target, x_target_traj = self.sde_bs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj)
             else:
                 raise NotImplementedError
         if recod_traj:

@@ -143,6 +143,8 @@ class DINOv2Encoder:
             if t.dtype not in (torch.uint8, torch.float32):
                 t = t.float()
             tens.append(t)
+        if any(t.dtype != tens[0].dtype for t in tens):     # the engine reads every batch with ONE element type
+            tens = [t.float() if t.dtype != torch.float32 else t for t in tens]
         return self.engine.forward(tens, nhwc=nhwc, pre_scale=pre, norm_mode=norm_mode)
 
     def forward(self, images):

@@ -25,6 +25,15 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
     import torch.distributed as dist
     total = 0
     by_key = {}
+    host_staged = dist.get_backend() == "gloo"     # gloo moves device tensors through host memory: do it explicitly, once per bucket
+
+    def bcast(t: torch.Tensor):
+        if host_staged and t.is_cuda:
+            h = t.cpu()
+            dist.broadcast(h, src)
+            t.copy_(h)
+        else:
+            dist.broadcast(t, src)
     for t in tensors:
         if t is None:
             continue
@@ -38,10 +47,10 @@ def broadcast_tensors(tensors: Iterable[torch.Tensor], src: int = 0, bucket_byte
             if not bucket:
                 return
             if len(bucket) == 1 and bucket[0].is_contiguous():
-                dist.broadcast(bucket[0], src)
+                bcast(bucket[0])
             else:
                 flat = torch.cat([b.reshape(-1) for b in bucket])
-                dist.broadcast(flat, src)
+                bcast(flat)
                 off = 0
                 for b in bucket:
                     b.copy_(flat[off:off + b.numel()].view_as(b))

@@ -276,13 +276,19 @@ class DinoEngine:
         """cams: list of image batches (same shape/dtype, fp32 or uint8) -> [ncams, B, hidden] fp32.
         Each camera batch gets its own max()/mean() decision (visual_encoder.py:78,100)."""
         x0 = cams[0]
-        is_u8 = x0.dtype == torch.uint8
+        is_u8 = all(c.dtype == torch.uint8 for c in cams)      # one element type per call: mixed batches are read as fp32
         cams = [c.to(self.device).contiguous() if is_u8 else c.to(self.device, torch.float32).contiguous() for c in cams]
         B = cams[0].shape[0]
         res = cams[0].shape[1] if nhwc else cams[0].shape[2]
         for c in cams:
-            assert c.shape == cams[0].shape
-            assert (c.shape[1] == c.shape[2]) if nhwc else (c.shape[2] == c.shape[3]), "square frames only"
+            if c.dim() != 4 or c.shape != cams[0].shape:
+                raise ValueError(f"DinoEngine.forward: every camera batch must be 4-D with one shape, got {[tuple(k.shape) for k in cams]}")
+            if (c.shape[-1] if nhwc else c.shape[1]) != 3:
+                raise ValueError(f"DinoEngine.forward: expected 3 colour channels, got shape {tuple(c.shape)} (nhwc={nhwc})")
+            if not ((c.shape[1] == c.shape[2]) if nhwc else (c.shape[2] == c.shape[3])):
+                raise ValueError(f"DinoEngine.forward: square frames only, got shape {tuple(c.shape)}")
+        if res < self.patch:
+            raise ValueError(f"DinoEngine.forward: frames of {res} px are smaller than one {self.patch}-px patch")
         grid = res // self.patch
         n = len(cams)
         out = torch.empty(n, B, self.hidden, dtype=torch.float32, device=self.device)

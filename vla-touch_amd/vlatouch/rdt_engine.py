@@ -38,7 +38,7 @@ class RdtEngine:
         dev = self.device
         self.cfg = dict(hidden=hidden, depth=depth, heads=heads, horizon=horizon, action_dim=action_dim)
         self.hidden, self.horizon, self.action_dim, self.img_len, self.max_lang = hidden, horizon, action_dim, img_cond_len, max_lang_cond_len
-        self.state_dim = state_token_dim
+        self.state_dim, self.lang_dim, self.img_dim = state_token_dim, lang_token_dim, img_token_dim
         f32 = torch.float32
         w = lambda k: sd[k].detach().to(dev, dtype).contiguous()
         v = lambda k: sd[k].detach().to(dev, f32).contiguous()
@@ -86,13 +86,32 @@ class RdtEngine:
         except Exception:
             pass
 
+    @staticmethod
+    def _expect(name, t, shape):
+        """The C driver indexes raw pointers with the packed config: a wrong shape would read out of bounds (the reference
+        raises a broadcast / matmul error in the same situations), so every tensor is checked here."""
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"RdtEngine: {name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+
     def _ws_for(self, B, Llang):
         return self._ws.get(L.lib().vt_rdt_workspace_bytes(self._h, B, Llang))
 
     def forward(self, x, freq, t, lang_c, img_c, lang_mask=None) -> torch.Tensor:
         """RDT.forward: x [B, horizon+1, D], freq [B], t [B] or [1], lang_c [B,L,D], img_c [B,img_len,D] -> [B, horizon, out]."""
         dev, dt = self.device, self.dtype
+        if x.dim() != 3 or lang_c.dim() != 3:
+            raise ValueError(f"RdtEngine.forward: x and lang_c must be 3-D, got {tuple(x.shape)} and {tuple(lang_c.shape)}")
         B, Llang = x.shape[0], lang_c.shape[1]
+        if not 1 <= Llang <= self.max_lang:
+            raise ValueError(f"RdtEngine.forward: language length {Llang} outside 1..{self.max_lang}")
+        self._expect("x", x, (B, self.horizon + 1, self.hidden))
+        self._expect("lang_c", lang_c, (B, Llang, self.hidden))
+        self._expect("img_c", img_c, (B, self.img_len, self.hidden))
+        self._expect("freq", freq, (B,))
+        if lang_mask is not None:
+            self._expect("lang_mask", lang_mask, (B, Llang))
+        if torch.as_tensor(t).numel() not in (1, B):
+            raise ValueError(f"RdtEngine.forward: t must have 1 or {B} elements, got {torch.as_tensor(t).numel()}")
         x = x.to(dev, dt).contiguous()
         lang_c, img_c = lang_c.to(dev, dt).contiguous(), img_c.to(dev, dt).contiguous()
         freq = freq.to(dev, torch.float32).contiguous()
@@ -114,7 +133,24 @@ class RdtEngine:
         if prediction_type not in ("sample", "epsilon"):
             raise ValueError(f"Unsupported prediction type {prediction_type}")
         dev, dt = self.device, self.dtype
+        if lang_tokens.dim() != 3:
+            raise ValueError(f"RdtEngine.sample: lang_tokens must be [B, L, dim], got {tuple(lang_tokens.shape)}")
         B, Llang = lang_tokens.shape[0], lang_tokens.shape[1]
+        if not 1 <= Llang <= self.max_lang:
+            raise ValueError(f"RdtEngine.sample: language length {Llang} outside 1..{self.max_lang}")
+        if num_inference_steps < 1:
+            raise ValueError("RdtEngine.sample: num_inference_steps must be >= 1")
+        self._expect("lang_tokens", lang_tokens, (B, Llang, self.hidden if adapted else self.lang_dim))
+        self._expect("lang_attn_mask", lang_attn_mask, (B, Llang))
+        self._expect("img_tokens", img_tokens, (B, self.img_len, self.hidden if adapted else self.img_dim))
+        if adapted:
+            if state_tokens.numel() != B * self.hidden:
+                raise ValueError(f"RdtEngine.sample: adapted state token has shape {tuple(state_tokens.shape)}, expected [{B}, 1, {self.hidden}]")
+        else:
+            self._expect("state_tokens", state_tokens, (B, 1, self.state_dim))
+        self._expect("action_mask", action_mask, (B, 1, self.state_dim))
+        self._expect("ctrl_freqs", ctrl_freqs, (B,))
+        self._expect("x_init", x_init, (B, self.horizon, self.action_dim))
         ts, coef = dpm.schedule(num_train_timesteps, beta_schedule, num_inference_steps)
         ts_c = (C.c_float * len(ts))(*[float(t) for t in ts])
         coef_c = (C.c_float * coef.size)(*coef.reshape(-1).tolist())

@@ -328,3 +328,44 @@ def siglip_shapes(hidden: int, layers: int, inter: int, image_size: int = 384, p
     d["post_layernorm.weight"] = (D,)
     d["post_layernorm.bias"] = (D,)
     return d
+
+
+# ------------------------------------------------------------------ a synthetic controller (bench / smoke / tests)
+MODEL_ARGS = {
+    'interpolant_type': 'linear', 'gamma_type': '2^0.5*t(t-1)', 'epsilon_type': '1-t', 'prior_policy': 'vla',
+    'beta_max': 0.03, 'sde_type': 'vs', 'action_dim': 10, 'obs_dim': 256, 'obs_horizon': 1,
+    'net_type': 'unet1D_si', 'pretrain': False, 'context_frames': 2, 'horizon': 16,
+}
+
+
+def torch_state_dict(shapes, prefix: str = "", salt: str = ""):
+    import torch
+    return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in fill_state_dict(shapes, prefix, salt).items()}
+
+
+def unit_stats():
+    import torch
+    z, o = torch.zeros(10), torch.ones(10)
+    return dict(action_mins=z.clone(), action_maxs=o.clone(), vla_mins=z.clone(), vla_maxs=o.clone(), action_range=o.clone(), vla_range=o.clone())
+
+
+def build_controller(cls, precision: str, device="cuda:0", size: str = "small", stats=None, **kw):
+    """A DiffusionController (the mirror class `cls`) filled with the deterministic synthetic weights the goldens were made
+    with (no checkpoints exist offline): raw `net` params = salt "", EMA shadow params = salt "ema" — a sampler that
+    forgets to run under the EMA weights fails the goldens."""
+    c = DINOV2_CONFIGS[size]
+    ctrl = cls(state_dim=10, hidden_dim=256, image_model_path=f"facebook/dinov2-{size}", diffusion_steps=10, device=device,
+               model_args=dict(MODEL_ARGS), use_force=True, force_dim=3, precision=precision,
+               image_state_dict=torch_state_dict(dinov2_shapes(c["hidden"], c["layers"]), prefix=f"dinov2-{size}."), **kw)
+    latent = c["hidden"]
+    ctrl.state_encoder.load_state_dict(torch_state_dict(state_encoder_shapes(2 * latent + 13), prefix="state_encoder."))
+    ctrl.force_decoder.load_state_dict(torch_state_dict(force_decoder_shapes(), prefix="force_decoder."))
+    ctrl.diffusion_model.net.load_state_dict(torch_state_dict(si_net_shapes(10, 256), prefix="si.", salt=""))
+    ema = torch_state_dict(si_net_shapes(10, 256), prefix="si.", salt="ema")
+    ctrl.diffusion_model.ema.load_state_dict({"decay": 0.75, "num_updates": 0, "collected_params": None,
+                                              "shadow_params": [ema[k] for k in ctrl.diffusion_model.net.state_dict().keys()]})
+    ctrl.diffusion_model.net.to(device)
+    ctrl.diffusion_model.ema.to(device)
+    ctrl.state_encoder.to(device)
+    ctrl.stats = {k: v.to(device) for k, v in (stats if stats is not None else unit_stats()).items()}
+    return ctrl
