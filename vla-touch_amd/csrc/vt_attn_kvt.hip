@@ -184,6 +184,197 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   }
 }
 
+// ---- ring variant: the SAME math with the tile stream staged in HALF tiles (K half, Vt half: 8 KiB each) through a ring of RING
+// slots, DMA waits COUNTED (s_waitcnt vmcnt(2 * halves still wanted in flight)) and raw s_barrier, so that RING-1 half tiles stay in
+// flight across the barriers instead of the single whole tile the 2-stage kernel above keeps between two draining __syncthreads():
+// the kernel is bound by HBM latency x bytes in flight per CU (4 co-resident blocks; compute per tile is ~1/3 of the time a tile
+// takes to arrive), and 5 x 8 KiB per block is what 4 blocks per CU can hold in 160 KiB of LDS.
+// Per half h (h even: K of tile h/2, h odd: its Vt): [wait until half h landed] [barrier: everybody sees it and is done with half
+// h-1] [issue half h + RING-1 into the slot of half h-1] [consume half h].
+template <int RING>
+__global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParams p) {
+  constexpr int HALF = KT * 128;                     // 8 KiB
+  __shared__ __attribute__((aligned(16))) char smem[RING * HALF];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int part = p.parts > 1 ? blockIdx.x : 0;
+  const int q = (p.parts > 1 ? 0 : blockIdx.x * (nw * 16)) + wave * 16 + l15;
+  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
+  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + (long)h * p.T * 8192;
+  const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
+  const int row0 = b * p.Nk, row1 = row0 + p.Nk;
+  int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
+  if (p.parts > 1) {
+    const int nt = t_last - t_first + 1, per = (nt + p.parts - 1) / p.parts;
+    t_first += part * per;
+    t_last = min(t_last, t_first + per - 1);
+  }
+
+  Frag<bf16_t> qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  // retire the Q loads before the first DMA: an ordinary load still pending when the ring runs would make the compiler drain
+  // the whole queue (vmcnt(0)) at its first use
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[ks].v));
+
+  // a half tile = 8 pieces of 1 KiB (8 rows x 128 B); waves 0..3 issue 2 consecutive pieces each
+  const int r_in = lane >> 3, pch = lane & 7;
+  const int nh = t_first <= t_last ? 2 * (t_last - t_first + 1) : 0;
+  const bf16_t* hsrc = KV + (long)t_first * 8192;    // half hh of this block's range starts at hsrc + hh * 4096
+  auto stage_half = [&](int hh, int slot) {
+    if (wave >= 4) return;
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int i = wave * 2 + e;
+      const int r = i * 8 + r_in;
+      const int c = pch ^ ((r >> 1) & 7);
+      __builtin_amdgcn_global_load_lds((glb_void*)(hsrc + (long)hh * 4096 + r * 64 + c * 8), (lds_void*)(smem + slot * HALF + i * 1024), 16, 0, 0);
+    }
+  };
+  // wait until half hh has landed (this wave's pieces), leaving the younger halves in flight; then the block-wide barrier
+  auto arrive = [&](int hh) {
+    const int rem = min(RING - 2, nh - 1 - hh);      // halves younger than hh that are already issued
+    if (rem >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if (rem == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (rem == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  static_assert(RING >= 3 && RING <= 5, "vmcnt table above covers up to 3 younger halves");
+
+  float4_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float cscale = p.scale * 1.4426950408889634f;
+
+#pragma unroll
+  for (int hh = 0; hh < RING - 1; ++hh)
+    if (hh < nh) stage_half(hh, hh);
+  int slot = 0;                                       // slot of the half being consumed
+  auto next_slot = [&](int s_) { return s_ + 1 == RING ? 0 : s_ + 1; };
+  auto prev_slot = [&](int s_) { return s_ == 0 ? RING - 1 : s_ - 1; };
+
+  for (int tile = t_first; tile <= t_last; ++tile) {
+    const int hh = 2 * (tile - t_first);
+    const int key0 = tile * KT;
+    const bool partial = key0 < row0 || key0 + KT > row1;     // block-uniform
+    // ---------------- K half
+    arrive(hh);
+    if (hh + RING - 1 < nh) stage_half(hh + RING - 1, prev_slot(slot));
+    const char* Ks = smem + slot * HALF;
+    float4_t sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        Frag<bf16_t> kf;
+        lds_frag(kf, Ks, kt * 16 + l15, ks * 4 + g);
+        mma16(sacc[kt], kf, qf[ks]);
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
+    if (km || partial) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kidx = key0 + kt * 16 + g * 4 + r;
+          bool ok = kidx >= row0 && kidx < row1;
+          if (ok && km) ok = km[kidx - row0] != 0;
+          if (!ok) sv[kt * 4 + r] = -INFINITY;
+        }
+    }
+    float mx = sv[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new != m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+    l_run += psum;
+    Frag<bf16_t> pf[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      uint4 pw;
+      pw.x = pk_bf16(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
+      pw.y = pk_bf16(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
+      pw.z = pk_bf16(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
+      pw.w = pk_bf16(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
+      pf[kb].v = __builtin_bit_cast(short8_t, pw);
+    }
+    slot = next_slot(slot);
+    // ---------------- Vt half
+    arrive(hh + 1);
+    if (hh + RING < nh) stage_half(hh + RING, prev_slot(slot));
+    const char* Vs = smem + slot * HALF;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        Frag<bf16_t> vf;
+        lds_frag(vf, Vs, dt * 16 + l15, kb * 4 + g);
+        if (partial) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int kidx = key0 + kb * 32 + (j >> 2) * 16 + g * 4 + (j & 3);
+            if (kidx < row0 || kidx >= row1) vf.v[j] = 0;
+          }
+        }
+        mma16(o[dt], vf, pf[kb]);
+      }
+    slot = next_slot(slot);
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (p.parts > 1) {
+    float* W = p.part_ws + ((((long)b * p.H + h) * p.parts + part) * (nw * 16) + wave * 16 + l15) * 66;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) W[dt * 16 + g * 4 + r] = o[dt][r];
+    if (g == 0) { W[64] = m_run; W[65] = l; }
+    return;
+  }
+  const float inv = 1.0f / l;
+  if (q < p.Nq) {
+    bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 t;
+      t.x = pk_bf16(o[dt][0] * inv, o[dt][1] * inv);
+      t.y = pk_bf16(o[dt][2] * inv, o[dt][3] * inv);
+      *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = t;
+    }
+  }
+}
+
 // merge the key-range parts of a (batch, head): O = sum_p e^{(m_p - m) c} o_p / sum_p e^{(m_p - m) c} l_p, c = scale*log2(e) (exp2 domain, as above)
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_ws, bf16_t* __restrict__ O, long o_bs, long o_rs, int H, int Nq, int rows_pad,
                                                           int parts, float cscale) {
@@ -256,15 +447,23 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
     if (padded < best) { best = padded; nw = w; }
   }
   const int qblocks = (p.Nq + nw * 16 - 1) / (nw * 16);
+  // VLATOUCH_ATTN_RING: 0 = the 2-stage whole-tile kernel, 4 / 5 = half-tile ring with counted waits (default 5)
+  static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
+#define VT_KVT_GO(grid) \
+  do { if (ring == 5) hipLaunchKernelGGL(attn_kvt_ring_kernel<5>, grid, dim3(64 * nw), 0, s, p); \
+       else if (ring == 4) hipLaunchKernelGGL(attn_kvt_ring_kernel<4>, grid, dim3(64 * nw), 0, s, p); \
+       else if (ring == 3) hipLaunchKernelGGL(attn_kvt_ring_kernel<3>, grid, dim3(64 * nw), 0, s, p); \
+       else hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p); } while (0)
   if (p.parts > 1) {
     if (qblocks != 1 || !p.part_ws) return VT_ERR_ARG;
-    hipLaunchKernelGGL(attn_kvt_kernel, dim3(p.parts, p.H, p.B), dim3(64 * nw), 0, s, p);
+    VT_KVT_GO(dim3(p.parts, p.H, p.B));
     hipLaunchKernelGGL(attn_combine_kernel, dim3(1, p.H, p.B), dim3(256), 0, s, p.part_ws, (bf16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
                        p.scale * 1.4426950408889634f);
     return vt_check_launch();
   }
   dim3 grid(qblocks, p.H, p.B);
-  hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p);
+  VT_KVT_GO(grid);
+#undef VT_KVT_GO
   return vt_check_launch();
 }
 

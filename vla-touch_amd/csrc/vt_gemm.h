@@ -30,6 +30,7 @@ struct VtGemmParams {
   // output mapping of the cached-condition K / V projections (large-GEMM path, 16-bit C, N % 64 == 0, no residual):
   // row m (all samples of the batch back to back), column n = h*64 + d go to the per-head tile stream of vt_attn_kvt.hip,
   //   tile(h, t = m/64) = C + ((h*cmap_T + t) * 2) * 4096 elements:  [K: 64 rows x 64 d][Vt: 64 d x 64 rows in MFMA k order]
-  // cmap 0 = plain row-major C; 1 = K part; 2 = Vt part (written transposed from the epilogue patch).  cmap_T = ceil(M/64).
+  // cmap 0 = plain row-major C; 1 = K part; 2 = Vt part (written transposed from the epilogue patch); 3 = fused K|V projection
+  // (N = 2*D: columns [0, D) -> K part, columns [D, 2D) -> Vt part of head (n - D)/64).  cmap_T = ceil(M/64).
   int cmap, cmap_T;
 };

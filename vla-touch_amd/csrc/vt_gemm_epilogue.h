@@ -17,7 +17,7 @@ constexpr int EP_BYTES = 64 * EPT_LD * 4;      // per-wave patch: max(32 x EP_LD
 // one row segment of the read-back: 4 consecutive columns n..n+3 of row m, raw accumulator values in x
 template <typename TC, int CMAP, bool ACT>
 __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, const float4 b4, const float4 cs4, const float* hw, const float4 hw4,
-                                               TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok) {
+                                               TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok) {   // CMAP here is 0 or 1
   float o[4] = {x.x + b4.x, x.y + b4.y, x.z + b4.z, x.w + b4.w};
   if (hw) {   // per-head RMSNorm over the row's 64 columns = the 16 lanes sharing lane>>4 (wave-uniform branch; all lanes shuffle)
     float s = o[0] + o[1] + o[2] + o[3];
@@ -59,9 +59,10 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
   }
 }
 
+// hcol0: the column the tile-stream head index is taken from (== ncol0 except for the V half of a fused K|V projection, CMAP 3)
 template <typename TC, int TM, int CMAP>
-__device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t (&acc)[4][TM], float* ep, const int grp, const int mrow0,
-                                                 const int ncol0, const int lane) {
+__device__ __forceinline__ void vt_gemm_epilogue_impl(const VtGemmParams& p, float4_t (&acc)[4][TM], float* ep, const int grp, const int mrow0,
+                                                      const int ncol0, const int hcol0, const int lane) {
   const int g = lane >> 4, l15 = lane & 15;
   const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
   const float* hw = nullptr;
@@ -98,7 +99,7 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
     if constexpr (sizeof(TC) == 2 && CMAP == 2) {
       // Vt tiles (bias only): 8 lanes cover the patch's 32 rows (= 32 keys, half a tile) of one d row as one 64-byte segment,
       // 8 d rows per instruction; a lane's 4 keys are an aligned group, contiguous in the tile's k order (vt_kpos).
-      const long tbase = (long)(ncol0 >> 6) * p.cmap_T;
+      const long tbase = (long)(hcol0 >> 6) * p.cmap_T;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
         const int dd = it * 8 + (lane >> 3), kq = (lane & 7) * 4;
@@ -132,5 +133,20 @@ __device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t
         }
       }
     }
+  }
+}
+
+
+// CMAP 3: fused K|V projection of a cached condition (N = 2*D: columns [0, D) are K — bias, k_norm, K tiles —, columns [D, 2D) are
+// V — bias, Vt tiles); a wave's 64 columns are one head of one half, so the choice is wave-uniform.
+template <typename TC, int TM, int CMAP>
+__device__ __forceinline__ void vt_gemm_epilogue(const VtGemmParams& p, float4_t (&acc)[4][TM], float* ep, const int grp, const int mrow0,
+                                                 const int ncol0, const int lane) {
+  if constexpr (CMAP == 3) {
+    const int half = p.N >> 1;
+    if (ncol0 < half) vt_gemm_epilogue_impl<TC, TM, 1>(p, acc, ep, grp, mrow0, ncol0, ncol0, lane);
+    else vt_gemm_epilogue_impl<TC, TM, 2>(p, acc, ep, grp, mrow0, ncol0, ncol0 - half, lane);
+  } else {
+    vt_gemm_epilogue_impl<TC, TM, CMAP>(p, acc, ep, grp, mrow0, ncol0, ncol0, lane);
   }
 }

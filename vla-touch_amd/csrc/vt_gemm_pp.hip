@@ -179,6 +179,7 @@ int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s) {
   const bool c16 = p.c_dtype != VT_F32;
   if (p.cmap == 1) VT_PP_GO(bf16_t, bf16_t, 1);
   else if (p.cmap == 2) VT_PP_GO(bf16_t, bf16_t, 2);
+  else if (p.cmap == 3) VT_PP_GO(bf16_t, bf16_t, 3);
   else if (p.a_dtype == VT_BF16) { if (c16) VT_PP_GO(bf16_t, bf16_t, 0); else VT_PP_GO(bf16_t, float, 0); }
   else { if (c16) VT_PP_GO(half_t, half_t, 0); else VT_PP_GO(half_t, float, 0); }
 #undef VT_PP_GO

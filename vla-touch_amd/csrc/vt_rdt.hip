@@ -240,16 +240,14 @@ int cache_cond(RCtx& c) {
       // bf16: K (k_norm fused) and V go straight from the GEMM epilogues into the tile stream when the projection takes the
       // large-GEMM path; small shapes go row-major through tmpA / tmpB and the retile kernels.
       const int T = lpad64(c.B * Lc) / 64;
-      VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
-      VtGemmParams pv = lin(src, d.adt, D, (const char*)b.ckv_w + (size_t)D * D * c.a, d.cdt, D, b.ckv_b + D, kv, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
-      pk.cmap = 1; pv.cmap = 2;
-      pk.cmap_T = pv.cmap_T = T;
-      if (fuse_headnorm(pk, b.ckn, D, nullptr, D, d.rms_mode) && vt_gemm_fast_eligible(pv)) {
-        CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
-        CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));
+      // one launch per layer: K | V fused (N = 2D), both halves of the tile stream written from ONE pass over the condition rows
+      VtGemmParams pkv = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
+      pkv.cmap = 3; pkv.cmap_T = T;
+      if (fuse_headnorm(pkv, b.ckn, D, nullptr, D, d.rms_mode)) {
+        CK(vt_wrap(vt_gemm_launch(pkv, c.s), "rdt cond kv"));
       } else {
-        pk.cmap = pv.cmap = 0; pk.hn_w0 = pk.hn_w1 = nullptr;
-        pk.C = c.ws + c.w.tmpA; pv.C = c.ws + c.w.tmpB;
+        VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, c.ws + c.w.tmpA, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
+        VtGemmParams pv = lin(src, d.adt, D, (const char*)b.ckv_w + (size_t)D * D * c.a, d.cdt, D, b.ckv_b + D, c.ws + c.w.tmpB, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
         CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
         CK(vt_k_headnorm(c.ws + c.w.tmpA, d.adt, D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
         CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));

@@ -119,9 +119,12 @@ class StochasticInterpolants:
         if noise is None:   # the reference's `self.d * torch.randn_like(current_x)` draws, made up-front
             noise = torch.randn((n_steps,) + tuple(x_initial.shape), dtype=torch.float32, device=dev)
         eng = self._sampler_engine(nets, dev)
-        xT, traj = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,
-                              gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code)
-        return xT, ([traj[i] for i in range(traj.shape[0])] if traj is not None else None)
+        res = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,
+                         gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code)
+        if not record:       # the hot path: no trajectory buffer, no per-step copies
+            return res, None
+        xT, traj = res
+        return xT, [traj[i] for i in range(traj.shape[0])]
 
     def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True):
         return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise, record)
