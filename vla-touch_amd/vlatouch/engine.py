@@ -35,14 +35,19 @@ def precision_dtypes(precision: str):
 
 
 class _Workspace:
+    """Scratch buffer of an engine, ONE PER HIP STREAM: calls enqueued on different streams (two batches in flight, bench.py
+    --streams) must not share scratch, calls on one stream are ordered and do."""
+
     def __init__(self, device):
         self.device = device
-        self.buf: Optional[torch.Tensor] = None
+        self.bufs: Dict[int, torch.Tensor] = {}
 
     def get(self, nbytes: int) -> torch.Tensor:
-        if self.buf is None or self.buf.numel() < nbytes:
-            self.buf = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
-        return self.buf
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self.bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = self.bufs[key] = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=self.device)
+        return buf
 
 
 # =========================================================================================== U-Net / SI sampler
