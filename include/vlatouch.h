@@ -190,6 +190,24 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
                   int n_steps, const float* timesteps, const float* coef, int sample_pred, int adapted, float* out,
                   int B, int L, void* workspace, vt_stream_t stream);
 
+/* ---------------------------------------------------------------- GelSight marker tracker -> m_t
+ * Replaces EnhancedMarkerTracker.init_standard / detect_markers / match_and_compute_displacement / estimate_force
+ * (residual_controller/tactile/marker/marker_tracker.py:81-114, 154-183, 308-341, 343-373) for a BATCH of frames.
+ * frames [N][H][W][channels] bytes (channels 3 = BGR as cv2 delivers it, 1 = gray).  Per frame: 5x5 blur -> adaptive
+ * Gaussian threshold (11, C = 2, inverted) -> 3x3 open -> outer contours of the 8-connected components -> polygon area in
+ * (min_area, max_area) -> truncated polygon centroid, in cv2.findContours order (last found first).
+ * markers [N][max_markers][2] int32 (x, y), counts [N] (may exceed max_markers or max_cand: overflow, the caller checks),
+ * binary_out [N][H][W] bytes (0/1; the reference's `processed_frame` / 255) or NULL.  input_is_binary != 0: `frames` is
+ * already a processed binary image [N][H][W] (non-zero = marker), only the contour stage runs (detect_markers :154). */
+size_t vt_marker_workspace_bytes(int N, int H, int W, int max_cand);
+int vt_marker_detect(const uint8_t* frames, int channels, int input_is_binary, int N, int H, int W, double min_area, double max_area,
+                     int max_cand, int* markers, int* counts, int max_markers, uint8_t* binary_out, void* workspace,
+                     vt_stream_t stream);
+/* baseline [n_base][2] int32 -> disp [N][max_markers][2] int32 (marker - nearest baseline marker, ties to the lower index),
+ * force [N][3] fp64 = |mean displacement|, unit direction x, y (zeros when no marker). */
+int vt_marker_displacement(const int* markers, const int* counts, int N, int max_markers, const int* baseline, int n_base,
+                           int* disp, double* force, vt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

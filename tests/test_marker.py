@@ -1,0 +1,147 @@
+"""GelSight marker tracker.  Golden g12 = outputs of the REFERENCE class
+(/root/reference/VLA/residual_controller/tactile/marker/marker_tracker.py::EnhancedMarkerTracker) driven in the build container
+through a stand-in `cv2` module made of oracle/marker.py's restated OpenCV primitives (tools/make_golden_marker.py): it pins
+the class logic; the primitives themselves are third party and unpinned (oracle/marker.py header).
+  CPU: the oracle's own composition == the reference class's outputs; primitive sanity checks.
+  GPU: the device tracker == golden / oracle, bit-exact (integer and fp64 work), incl. the batched stream API and edge cases."""
+import numpy as np
+import pytest
+import torch
+
+from tests import cases
+from oracle import marker as M
+from tools.make_golden_marker import frames as golden_frames, MOTION
+
+
+def G():
+    return np.load(f"{cases.GOLDEN}/g12_marker.npz")
+
+
+def test_oracle_matches_reference_class_outputs():
+    g, fr = G(), golden_frames()
+    base = M.detect_markers(M.preprocess_standard(fr[0]))
+    assert np.array_equal(base, g["baseline"]) and len(base) == 63
+    for i, f in enumerate(fr):
+        proc = M.preprocess_standard(f)
+        assert int(proc.astype(np.int64).sum()) == int(g[f"binary_sum_{i}"])
+        cur = M.detect_markers(proc)
+        assert np.array_equal(cur, g[f"markers_{i}"])
+        disp = M.match_displacement(cur, base)
+        assert np.array_equal(disp, g[f"disp_{i}"])
+        mag, d = M.estimate_force(disp)
+        assert np.allclose([mag, d[0], d[1]], g[f"force_{i}"], rtol=0, atol=1e-12)
+    # the synthetic motion is recovered to about a pixel (sanity of the whole chain, not a parity statement)
+    for i, ((sx, sy), bulge) in enumerate(MOTION):
+        mean = g[f"disp_{i}"].mean(0)
+        assert abs(mean[0] - sx) < 1.0 and abs(mean[1] - sy) < 1.0, (i, mean)
+
+
+def test_oracle_primitives_known_answers():
+    # BGR -> gray fixed point: pure colours (OpenCV documents Y = 0.299 R + 0.587 G + 0.114 B)
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], dtype=np.uint8)
+    assert M.bgr2gray(px).tolist() == [[29, 150, 76, 255]]
+    # binomial blur of an impulse of 256 -> the [1 4 6 4 1]^2 / 256 kernel itself (x256/256 rounded), constant stays constant
+    imp = np.zeros((9, 9), dtype=np.uint8); imp[4, 4] = 255
+    b = M.gaussian_blur5_u8(imp)
+    assert b[4, 4] == (36 * 255 + 128) >> 8 and b[4, 2] == (6 * 255 + 128) >> 8 and b[2, 2] == (255 + 128) >> 8
+    assert (M.gaussian_blur5_u8(np.full((7, 9), 93, np.uint8)) == 93).all()
+    # polygon moments: 5 x 3 pixel rectangle -> contour through pixel centres has area 4 x 2 and centroid at its middle
+    r = np.zeros((8, 10), np.uint8); r[2:5, 3:8] = 255
+    (c,) = M.external_contours(r)
+    m00, m10, m01 = M.contour_moments(c)
+    assert m00 == 8.0 and m10 / m00 == 5.0 and m01 / m00 == 3.0
+    # opening removes a lone pixel and a 2-wide bar, keeps a 3x3 block
+    o = np.zeros((12, 12), np.uint8); o[1, 1] = 255; o[4:6, 2:9] = 255; o[8:11, 8:11] = 255
+    assert M.morph_open3(o).sum() == 9 * 255
+    # diagonal pixels are ONE 8-connected component
+    dg = np.zeros((6, 6), np.uint8); dg[1, 1] = dg[2, 2] = dg[3, 3] = 255
+    assert len(M.external_contours(dg)) == 1
+
+
+# ------------------------------------------------------------------ GPU
+gpu = pytest.mark.gpu
+
+
+def tracker():
+    from residual_controller.tactile.marker.marker_tracker import EnhancedMarkerTracker
+    return EnhancedMarkerTracker(grid_rows=7, grid_cols=9, device="cuda:0")
+
+
+@gpu
+def test_device_tracker_matches_reference_golden():
+    g, fr = G(), golden_frames()
+    tr = tracker()
+    base = tr.calibrate(fr[0])
+    assert np.array_equal(base, g["baseline"])
+    assert np.allclose(tr.ideal_grid, g["ideal_grid"])
+    for i, f in enumerate(fr):
+        proc = tr.preprocess_frame(f)
+        assert proc.dtype == np.uint8 and int(proc.astype(np.int64).sum()) == int(g[f"binary_sum_{i}"])
+        assert np.array_equal(proc, M.preprocess_standard(f))
+        cur = tr.detect_markers(proc)
+        assert np.array_equal(cur, g[f"markers_{i}"])
+        disp = tr.get_marker_state(f)
+        assert np.array_equal(disp, g[f"disp_{i}"])
+        mag, d = tr.estimate_force(disp)
+        assert np.allclose([mag, d[0], d[1]], g[f"force_{i}"], rtol=0, atol=1e-12)
+
+
+@gpu
+def test_device_tracker_batched_stream_equals_frame_by_frame():
+    g, fr = G(), golden_frames()
+    tr = tracker()
+    disp, mag, direction = tr.track_frames(np.stack(fr))
+    assert np.array_equal(tr.baseline_markers, g["baseline"])
+    for i in range(len(fr)):
+        n = int(tr.last_counts[i])
+        assert np.array_equal(disp[i, :n], g[f"disp_{i}"])
+        assert np.allclose([mag[i], direction[i, 0], direction[i, 1]], g[f"force_{i}"], rtol=0, atol=1e-12)
+
+
+@gpu
+@pytest.mark.parametrize("H,W", [(240, 320), (97, 131), (33, 40)])
+def test_device_tracker_vs_oracle_random_blobs_and_edges(H, W):
+    """Ragged sizes (not multiples of the 32-pixel tile), blobs touching the image border, specks under / over the area
+    filter, a blank frame, a gray (1-channel) frame; against the oracle run live."""
+    rng = np.random.default_rng(H * 1000 + W)
+    tr = tracker()
+    frames = []
+    for k in range(4):
+        f = np.full((H, W, 3), 170, np.float64) + rng.normal(0, 3, (H, W, 3))
+        yy, xx = np.mgrid[0:H, 0:W]
+        n = 0 if k == 3 else 12
+        for _ in range(n):
+            cx, cy, r = rng.uniform(-2, W + 2), rng.uniform(-2, H + 2), rng.uniform(1.0, 9.0)
+            f *= (1 - 0.8 * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r)))[..., None]
+        frames.append(np.clip(np.rint(f), 0, 255).astype(np.uint8))
+    for f in frames:
+        proc = tr.preprocess_frame(f)
+        ref = M.preprocess_standard(f)
+        assert np.array_equal(proc, ref)
+        tr.expected_markers = 10 ** 6                     # the raw candidate list, whatever its length
+        got = tr.detect_markers(proc)
+        want = M.detect_markers(ref)
+        assert np.array_equal(np.asarray(got).reshape(-1, 2), want)
+        # the contour stage alone, from a foreign binary image
+        again = tr.detect_markers(ref.copy())
+        assert np.array_equal(np.asarray(again).reshape(-1, 2), want)
+    gray = M.bgr2gray(frames[0])
+    assert np.array_equal(tr.preprocess_frame(gray), M.preprocess_standard(gray))
+    tr2 = tracker()
+    with pytest.raises(ValueError):
+        tr2.preprocess_frame(frames[0].astype(np.float32))
+    tr2.gelsight_version = "HSR"
+    with pytest.raises(NotImplementedError):
+        tr2.preprocess_frame(frames[0])
+
+
+@gpu
+def test_device_displacement_ties_empty_and_force():
+    tr = tracker()
+    tr.baseline_markers = np.array([[10, 10], [20, 10], [10, 20]], dtype=np.int64)
+    cur = np.array([[15, 10], [11, 21], [40, 40]], dtype=np.int64)          # first marker is equidistant to baseline 0 and 1 -> lower index
+    d = tr.match_and_compute_displacement(cur)
+    assert np.array_equal(d, M.match_displacement(cur, tr.baseline_markers))
+    assert len(tr.match_and_compute_displacement(np.zeros((0, 2), np.int64))) == 0
+    mag, d = tr.estimate_force(np.array([]))
+    assert mag == 0 and np.array_equal(d, [0, 0])

@@ -147,6 +147,9 @@ SIGNATURES = {
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vt_rdt_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
+    "vt_marker_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "vt_marker_detect": (_I, [_P, _I, _I, _I, _I, _I, C.c_double, C.c_double, _I, _P, _P, _I, _P, _P, _P]),
+    "vt_marker_displacement": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P]),
 }
 
 
