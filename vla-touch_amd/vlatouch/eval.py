@@ -6,8 +6,9 @@ Restates (host-side data plumbing, numpy):
   * `ControllerDataset.create_index_mapping / __getitem__ / get_normalization_stats`
                                                                       VLA/residual_controller/controller_dataset.py:71-236
   * `test_diffusion_controller` metrics                               VLA/residual_controller/bridge_test.py:111-197
-The refinement itself is `controller.predict` (HIP engines).  Episodes are read from NPZ files (keys below) or, when h5py is
-installed, from the reference's `episode_*.h5` layout (data/franka_data/4_convert_to_hdf5.py) with the same key names:
+The refinement itself is `controller.predict` (HIP engines).  Episodes are read from the reference's `episode_*.h5` files (LZF-
+compressed HDF5 as written by data/franka_data/4_convert_to_hdf5.py / create_controller_dataset_episode.py, parsed by
+vlatouch/h5lite.py) or from NPZ files with the same key names:
     ee_poses [N,7] (xyz + quaternion xyzw), gripper_pos [N], vla_action [N,64,10],
     gelsight_force/forces [N,3], gelsight_force/displacement [N,63,2] (optional), camera1_resized / camera2_resized [N,res,res,3] uint8
 """
@@ -55,12 +56,9 @@ def load_episode(path: str) -> Dict[str, np.ndarray]:
         z = np.load(path)
         ep = {k: z[k] for k in z.files}
     else:
-        try:
-            import h5py
-        except ImportError as e:       # pragma: no cover
-            raise ImportError("reading .h5 episodes needs h5py; convert to .npz with the same keys") from e
+        from . import h5lite       # the product's own reader of the reference's LZF-compressed episode files (no h5py needed)
         ep = {}
-        with h5py.File(path, "r") as f:
+        with h5lite.File(path, "r") as f:
             for k in ("ee_poses", "gripper_pos", "vla_action", "camera1_resized", "camera2_resized"):
                 if k in f:
                     ep[k] = f[k][:]
