@@ -1,5 +1,5 @@
 """vlatouch.h5lite — the product's HDF5 reader / writer for the reference's episode files.
-Pinned to REAL h5py output: tests/golden/episodes/*.h5 were written by h5py 3.3.0 / HDF5 1.10.6 exactly the way the reference
+Pinned to REAL h5py output: tests/golden/episodes_h5/*.h5 were written by h5py 3.3.0 / HDF5 1.10.6 exactly the way the reference
 writes episodes (tools/make_h5_fixtures.py: create_dataset(..., compression='lzf'), groups per sensor).  The writer is checked
 by reading its files back with the real h5py where that interpreter exists (/opt/conda/bin/python3.9 in this image)."""
 import os
@@ -14,6 +14,7 @@ from vlatouch import h5lite as H
 from vlatouch import convert, eval as ev
 
 EP = os.path.join(cases.GOLDEN, "episodes")
+EPH = os.path.join(cases.GOLDEN, "episodes_h5")
 PY39 = "/opt/conda/bin/python3.9"
 have_h5py = os.path.exists(PY39) and subprocess.run([PY39, "-c", "import h5py"], capture_output=True).returncode == 0
 
@@ -21,7 +22,7 @@ have_h5py = os.path.exists(PY39) and subprocess.run([PY39, "-c", "import h5py"],
 @pytest.mark.parametrize("name", ["episode_1", "episode_2"])
 def test_reads_real_h5py_lzf_episode(name):
     z = np.load(os.path.join(EP, f"{name}.npz"))
-    with H.File(os.path.join(EP, f"{name}.h5")) as f:
+    with H.File(os.path.join(EPH, f"{name}.h5")) as f:
         assert set(f.keys()) == {"ee_poses", "gripper_pos", "vla_action", "gelsight_force", "camera1_resized", "camera2_resized", "instruct_embeddings"}
         assert isinstance(f["gelsight_force"], H.Group) and set(f["gelsight_force"].keys()) == {"forces", "displacement"}
         for k in z.files:
@@ -33,7 +34,7 @@ def test_reads_real_h5py_lzf_episode(name):
         with pytest.raises(KeyError):
             f["nope"]
     # the evaluation harness reads the .h5 episode exactly like the .npz one
-    a, b = ev.load_episode(os.path.join(EP, f"{name}.h5")), ev.load_episode(os.path.join(EP, f"{name}.npz"))
+    a, b = ev.load_episode(os.path.join(EPH, f"{name}.h5")), ev.load_episode(os.path.join(EP, f"{name}.npz"))
     for k in b:
         assert np.array_equal(a[k], b[k]), k
     assert ev.episode_windows(a, 2, 8) == ev.episode_windows(b, 2, 8)
@@ -48,7 +49,7 @@ def test_reads_other_storage_forms_written_by_h5py():
         "incompressible_lzf": rng.integers(0, 255, (4, 4096), dtype=np.uint8),
         "edge_chunks_f64": rng.standard_normal((10, 7, 3)),
     }
-    with H.File(os.path.join(EP, "storage_forms.h5")) as f:
+    with H.File(os.path.join(EPH, "storage_forms.h5")) as f:
         for k, v in want.items():
             assert np.array_equal(f[k][...], v), k
         assert f["gz_shuffle_i16"].compression == "gzip" and f["contiguous_f32"].chunks is None

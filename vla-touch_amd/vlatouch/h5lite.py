@@ -4,7 +4,7 @@ The reference stores episodes with h5py: `create_dataset(name, data=..., compres
 (VLA/data/franka_data/4_convert_to_hdf5.py:30-167; read back in residual_controller/controller_dataset.py:71-170 and
 data/create_controller_dataset_episode.py:161-213).  h5py / libhdf5 are not available to the deployment interpreter, so
 this module restates the published HDF5 file format (HDF5 File Format Specification v2/v3) for exactly what those files
-contain, and is pinned to REAL h5py output by tests/golden/episodes/*.h5 (written by h5py 3.3.0 / HDF5 1.10.6,
+contain, and is pinned to REAL h5py output by tests/golden/episodes_h5/*.h5 (written by h5py 3.3.0 / HDF5 1.10.6,
 tools/make_h5_fixtures.py):
   read : superblock v0-v3, v1 object headers (+ continuation blocks), v2 object headers without creation-order / fractal
          heaps, old-style groups (symbol table: v1 B-tree + local heap + SNOD), datasets with contiguous / compact /
