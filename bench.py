@@ -122,7 +122,7 @@ def main():
     if args.workload in ("full", "rdt"):
         from models.rdt_runner import RDTRunner
         rdt_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
-        cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
+        cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": "meansq"}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
                "state_adaptor": "mlp3x_gelu",
                "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": args.rdt_steps, "beta_schedule": "squaredcos_cap_v2",
                                    "prediction_type": "sample", "clip_sample": False}}
@@ -311,7 +311,7 @@ def main():
     except Exception:
         pass
 
-    def roof(mode, name):
+    def roof(mode, name, pmc_key):
         ms_, fl_, by_, n_ = prof[mode]
         if n_ <= 0 or ms_ <= 0:
             return None
@@ -320,7 +320,7 @@ def main():
                 "frac": round(tf / PEAK_BF16_TFLOPS, 4), "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2),
                 "algorithmic_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
                 "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3),
-                "traffic": (round(pmc[name.split(" ")[0]]["per_launch_bytes"] / 1e9, 4) if name.split(" ")[0] in pmc else None),
+                "traffic": (round(pmc[pmc_key]["per_launch_bytes"] / 1e9, 4) if pmc_key in pmc else None),
                 "traffic_unit": "GB per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
                 "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4)}
     # on-box measured peaks (report fractions of the nominal AND of a measured peak): a large square bf16 GEMM on the
@@ -350,8 +350,10 @@ def main():
                      "d2d_copy_GBs": round(5 * 2 * src.numel() * 4 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e9, 1)}
             del a8, w8, o8, src, dst
 
-    r_pp = roof(2, "gemm_pp256_kernel (256x256x64 ping-pong tile, 16-bit MFMA: condition K/V projections, image adaptor, DINOv2 Linears)")
-    r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)")
+    r_pp = roof(2, "gemm_pp256d_kernel (256x256x64 ping-pong tile, deep-prefetch schedule, 16-bit MFMA: fused condition K|V projections, image adaptor, "
+                   "RDT qkv projections, DINOv2 Linears)", "gemm_pp256")
+    r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)",
+                "gemm_ppk")
     if onbox is not None:
         res["onbox_peaks"] = onbox
         for r in (r_pp, r_gl):
