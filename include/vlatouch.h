@@ -144,16 +144,22 @@ int vt_concat_obs(const float* cls1, const float* cls2, int dv, const float* sta
                   int fdim, void* out, int odt, long ldo, int B, vt_stream_t stream);
 
 /* ---------------------------------------------------------------- LSTM residual head
- * Replaces TactileLSTMController.predict (lstm_step_controller.py:232-286), one control tick:
- * force MLP -> 2-layer LSTM cell with carried (h, c) -> head -> vla_n + delta -> denormalise('expert'). */
+ * Replaces TactileLSTMController.predict / predict_sequence / forward (lstm_step_controller.py:232-286, 288-319, 170-213):
+ * force MLP -> L-layer LSTM cell with carried (h, c) -> [h_top | obs_cond] head -> vla_n + delta, as ONE persistent kernel for T
+ * consecutive ticks (csrc/vt_lstm.hip).  hidden must be 256; weights pre-packed in MFMA fragment order by the host side
+ * (order and layout: csrc/vt_lstm.hip above vt_lstm_create).  force_pad / in_pad are kept for ABI stability and ignored. */
 typedef struct { int state_dim, hidden, layers, force_dim, force_pad, in_pad, cdt; } vt_lstm_desc;
 int vt_lstm_create(const vt_lstm_desc* desc, const void* const* weights, int n_weights, vt_lstm_t* out);
 void vt_lstm_destroy(vt_lstm_t h);
 int vt_lstm_num_weights(const vt_lstm_desc* desc);
 size_t vt_lstm_workspace_bytes(vt_lstm_t h, int B);
-/* out_n[B][state_dim] = vla_n + delta (normalised); h, c: [layers][B][hidden] fp32, updated in place. */
+/* One tick: out_n[B][state_dim] = vla_n + delta (normalised); h, c: [layers][B][hidden] fp32, updated in place. */
 int vt_lstm_step(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c,
                  float* out_n, int B, void* workspace, vt_stream_t stream);
+/* T ticks in one launch: vla_n [B][T][state_dim], force [B][T][force_dim] -> out_n [B][T][state_dim]; (h, c) carried in LDS /
+ * registers across the ticks, read at entry and written back at exit. */
+int vt_lstm_sequence(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c,
+                     float* out_n, int B, int T, vt_stream_t stream);
 
 /* ---------------------------------------------------------------- RDT diffusion transformer + DPM-Solver++ sampler
  * Replaces RDT.forward (models/rdt/model.py:126-165; blocks models/rdt/blocks.py:72-202) and

@@ -1,4 +1,4 @@
-// vt_models.hip — host drivers: DINOv2 CLS encoder, small MLP chains, observation concat, LSTM residual head.
+// vt_models.hip — host drivers: DINOv2 CLS encoder, small MLP chains, observation concat.
 //
 // DINOv2 weight order (vt_dino_create):
 //   0 patch_w [D][kpad] cdt   1 patch_b [D]   2 cls_pos0 [D] (= cls_token + position_embeddings[0])
@@ -7,10 +7,7 @@
 //   then  lnf_w  lnf_b
 // The residual stream (tokens) is kept in fp32; normalised activations / QKV / MLP hidden are `adt`.
 //
-// LSTM weight order (vt_lstm_create):
-//   0 fe_w1 [H/2][force_pad] cdt  1 fe_b1  2 fe_w2 [H/2][H/2] cdt  3 fe_b2
-//   per layer: w_ih [4H][in_pad_l] cdt  w_hh [4H][H] cdt  b_ih  b_hh      (in_pad_0 = in_pad, else H)
-//   then head_w1 [H][2H] cdt  head_b1  ln_w  ln_b  head_w2 [state_dim][H] cdt  head_b2
+// (The LSTM residual head is one persistent kernel: vt_lstm.hip.)
 #include <math.h>
 #include <string.h>
 #include <new>
@@ -180,87 +177,5 @@ int vt_concat_obs(const float* cls1, const float* cls2, int dv, const float* sta
   CK(vt_k_place_cols(cls2, VT_F32, dv, out, odt, ldo, dv, B, dv, s));
   CK(vt_k_place_cols(state, VT_F32, sdim, out, odt, ldo, 2 * dv, B, sdim, s));
   if (forces && fdim > 0) CK(vt_k_place_cols(forces, VT_F32, fdim, out, odt, ldo, 2 * dv + sdim, B, fdim, s));
-  return VT_OK;
-}
-
-// ======================================================================================= LSTM residual head
-struct vt_lstm_s {
-  vt_lstm_desc d;
-  const void *fe_w1, *fe_w2, *w_ih[4], *w_hh[4], *head_w1, *head_w2;
-  const float *fe_b1, *fe_b2, *b_ih[4], *b_hh[4], *head_b1, *ln_w, *ln_b, *head_b2;
-};
-int vt_lstm_num_weights(const vt_lstm_desc* d) { return 4 + 4 * d->layers + 6; }
-int vt_lstm_create(const vt_lstm_desc* desc, const void* const* w, int n, vt_lstm_t* out) {
-  if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_lstm_create: null argument");
-  const vt_lstm_desc& d = *desc;
-  if (d.layers < 1 || d.layers > 4 || d.hidden % 32 || d.in_pad % 16 || d.force_pad % 16) return vt_fail(VT_ERR_ARG, "vt_lstm_create: bad descriptor");
-  if (n != vt_lstm_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_lstm_create: expected %d weights, got %d", vt_lstm_num_weights(desc), n);
-  for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_lstm_create: weight %d is null", k);
-  vt_lstm_s* h = new (std::nothrow) vt_lstm_s();
-  if (!h) return vt_fail(-12, "out of host memory");
-  h->d = d;
-  int i = 0;
-  h->fe_w1 = w[i++]; h->fe_b1 = (const float*)w[i++]; h->fe_w2 = w[i++]; h->fe_b2 = (const float*)w[i++];
-  for (int l = 0; l < d.layers; ++l) { h->w_ih[l] = w[i++]; h->w_hh[l] = w[i++]; h->b_ih[l] = (const float*)w[i++]; h->b_hh[l] = (const float*)w[i++]; }
-  h->head_w1 = w[i++]; h->head_b1 = (const float*)w[i++]; h->ln_w = (const float*)w[i++]; h->ln_b = (const float*)w[i++];
-  h->head_w2 = w[i++]; h->head_b2 = (const float*)w[i++];
-  *out = h;
-  return VT_OK;
-}
-void vt_lstm_destroy(vt_lstm_t h) { delete h; }
-
-namespace {
-struct LWs { size_t fpad, f1, xin, gi, gh, hc, hd1, hd2, total; };
-LWs lcarve(const vt_lstm_s* h, int B) {
-  const vt_lstm_desc& d = h->d;
-  LWs w; size_t o = 0;
-  auto take = [&](size_t b) { size_t r = o; o += (b + 255) / 256 * 256; return r; };
-  w.fpad = take((size_t)B * d.force_pad * 4); w.f1 = take((size_t)B * d.hidden / 2 * 4);
-  w.xin = take((size_t)B * d.in_pad * 4);
-  w.gi = take((size_t)B * 4 * d.hidden * 4); w.gh = take((size_t)B * 4 * d.hidden * 4);
-  w.hc = take((size_t)B * 2 * d.hidden * 4); w.hd1 = take((size_t)B * d.hidden * 4); w.hd2 = take((size_t)B * d.hidden * 4);
-  w.total = o;
-  return w;
-}
-}  // namespace
-size_t vt_lstm_workspace_bytes(vt_lstm_t h, int B) { return h ? lcarve(h, B).total : 0; }
-
-int vt_lstm_step(vt_lstm_t hd, const float* obs_cond, const float* vla_n, const float* force, float* h, float* c, float* out_n, int B,
-                 void* workspace, vt_stream_t stream) {
-  if (!hd || !obs_cond || !vla_n || !force || !h || !c || !out_n || !workspace) return vt_fail(VT_ERR_ARG, "vt_lstm_step: null argument");
-  const vt_lstm_desc& d = hd->d;
-  hipStream_t s = (hipStream_t)stream;
-  char* ws = (char*)workspace;
-  const LWs w = lcarve(hd, B);
-  const int H = d.hidden, H2 = d.hidden / 2;
-  // activations stay fp32 (tiny, latency-bound); weights cdt
-  CK(vt_k_pad_cols(force, d.force_dim, ws + w.fpad, VT_F32, d.force_pad, B, s));
-  { VtGemmParams p = lin(ws + w.fpad, VT_F32, d.force_pad, hd->fe_w1, d.cdt, d.force_pad, hd->fe_b1, ws + w.f1, VT_F32, H2, B, H2, d.force_pad, VT_ACT_GELU_ERF);
-    CK(vt_wrap(vt_gemm_launch(p, s), "lstm force mlp 1")); }
-  if (hipMemsetAsync(ws + w.xin, 0, (size_t)B * d.in_pad * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "memset");
-  { VtGemmParams p = lin(ws + w.f1, VT_F32, H2, hd->fe_w2, d.cdt, H2, hd->fe_b2, ws + w.xin, VT_F32, d.in_pad, B, H2, H2, VT_ACT_NONE);
-    CK(vt_wrap(vt_gemm_launch(p, s), "lstm force mlp 2")); }
-  CK(vt_k_place_cols(vla_n, VT_F32, d.state_dim, ws + w.xin, VT_F32, d.in_pad, H2, B, d.state_dim, s));
-  const void* xin = ws + w.xin; int xk = d.in_pad;
-  for (int l = 0; l < d.layers; ++l) {
-    float* hl = h + (long)l * B * H;
-    float* cl = c + (long)l * B * H;
-    { VtGemmParams p = lin(xin, VT_F32, xk, hd->w_ih[l], d.cdt, xk, hd->b_ih[l], ws + w.gi, VT_F32, 4 * H, B, 4 * H, xk, VT_ACT_NONE);
-      CK(vt_wrap(vt_gemm_launch(p, s), "lstm w_ih")); }
-    { VtGemmParams p = lin(hl, VT_F32, H, hd->w_hh[l], d.cdt, H, hd->b_hh[l], ws + w.gh, VT_F32, 4 * H, B, 4 * H, H, VT_ACT_NONE);
-      CK(vt_wrap(vt_gemm_launch(p, s), "lstm w_hh")); }
-    CK(vt_k_lstm_cell((const float*)(ws + w.gi), (const float*)(ws + w.gh), hl, cl, B, H, s));
-    xin = hl; xk = H;
-  }
-  // head: cat(h_top, obs_cond) -> Linear -> LayerNorm -> GELU -> Linear ; + vla_n
-  CK(vt_k_place_cols(xin, VT_F32, H, ws + w.hc, VT_F32, 2 * H, 0, B, H, s));
-  CK(vt_k_place_cols(obs_cond, VT_F32, H, ws + w.hc, VT_F32, 2 * H, H, B, H, s));
-  { VtGemmParams p = lin(ws + w.hc, VT_F32, 2 * H, hd->head_w1, d.cdt, 2 * H, hd->head_b1, ws + w.hd1, VT_F32, H, B, H, 2 * H, VT_ACT_NONE);
-    CK(vt_wrap(vt_gemm_launch(p, s), "lstm head 1")); }
-  CK(vt_k_rownorm(ws + w.hd1, VT_F32, H, ws + w.hd2, VT_F32, H, hd->ln_w, hd->ln_b, B, H, 1e-5f, VT_NORM_LAYER, s));
-  CK(vt_k_act_copy(ws + w.hd2, VT_F32, H, ws + w.hd1, VT_F32, H, B, H, VT_ACT_GELU_ERF, s));
-  { VtGemmParams p = lin(ws + w.hd1, VT_F32, H, hd->head_w2, d.cdt, H, hd->head_b2, out_n, VT_F32, d.state_dim, B, d.state_dim, H, VT_ACT_NONE);
-    p.residual = vla_n; p.ldr = d.state_dim;
-    CK(vt_wrap(vt_gemm_launch(p, s), "lstm head 2")); }
   return VT_OK;
 }

@@ -70,7 +70,7 @@ class TactileLSTMController:
             mods = {"force_encoder": self.force_encoder.state_dict(), "lstm": self.lstm.state_dict(),
                     "output_head": self.output_head.state_dict()}
             self._engine = LstmEngine(mods, state_dim=self.state_dim, hidden=self.hidden_dim, layers=self.lstm.num_layers,
-                                      force_dim=self.force_dim, precision="fp32", device=self.device)
+                                      force_dim=self.force_dim, precision="fp32" if self.precision == "fp32" else "x3", device=self.device)
             self._engine_key = key
         return self._engine
 
@@ -105,13 +105,12 @@ class TactileLSTMController:
         B, T, _ = vla.shape
         saved = (self.hidden_state, self.cell_state)
         self.reset_state(B)
-        outs = []
         with torch.no_grad():
-            for t in range(T):
-                o = self._step_n(obs_cond, vla[:, t], forces[:, t])
-                outs.append(o if self.use_residual else o - vla[:, t].to(o.device))
+            o = self._lstm_engine().sequence(obs_cond, torch.as_tensor(vla), torch.as_tensor(forces), self.hidden_state, self.cell_state)
+            if not self.use_residual:
+                o = o - torch.as_tensor(vla).to(o.device)
         self.hidden_state, self.cell_state = saved
-        return torch.stack(outs, dim=1)
+        return o
 
     def predict(self, obs_cond, vla_action, force, initialize=False):
         """One tick: normalised vla_action [B, state_dim] + force [B, force_dim] -> refined action in expert scale
@@ -131,9 +130,14 @@ class TactileLSTMController:
         B, T, _ = vla_actions.shape
         self.reset_state(batch_size=B)
         vla_actions_n = normalize_actions(torch.as_tensor(vla_actions).to(self.device), self.stats, 'vla')
-        refined = [self.predict(obs_cond=obs_cond, vla_action=vla_actions_n[:, t], force=force_seq[:, t], initialize=(t == 0))
-                   for t in range(T)]
-        return torch.stack(refined, dim=1)
+        # the T ticks run as ONE persistent kernel with (h, c) carried on chip (vt_lstm_sequence) — same arithmetic as T calls of
+        # `predict` (the reference's loop, :300-317)
+        self.eval()
+        with torch.no_grad():
+            out_n = self._lstm_engine().sequence(obs_cond, vla_actions_n, torch.as_tensor(force_seq), self.hidden_state, self.cell_state)
+            if not self.use_residual:
+                out_n = out_n - vla_actions_n.to(out_n.device)
+            return denormalize_actions(out_n, self.stats, 'expert')
 
     def train(self, mode=True):
         for m in self.trainable_modules:

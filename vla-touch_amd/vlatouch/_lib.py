@@ -141,6 +141,7 @@ SIGNATURES = {
     "vt_lstm_num_weights": (_I, [_P]),
     "vt_lstm_workspace_bytes": (_Z, [_P, _I]),
     "vt_lstm_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _P, _P]),
+    "vt_lstm_sequence": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "vt_rdt_create": (_I, [_P, _P, _I, _P]),
     "vt_rdt_destroy": (None, [_P]),
     "vt_rdt_num_weights": (_I, [_P]),

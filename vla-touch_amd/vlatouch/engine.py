@@ -505,29 +505,50 @@ class LstmEngine:
     def __init__(self, mods: Mapping[str, SD], *, state_dim: int = 10, hidden: int = 256, layers: int = 2, force_dim: int = 3,
                  precision: str = "fp32", device="cuda"):
         self.device = L.require_gpu(device)
-        cdt, _ = precision_dtypes(precision)
+        cdt = L.F32X3 if precision == "x3" else precision_dtypes(precision)[0]     # "x3": fp32 weights as bf16 hi + lo (csrc/vt_lstm.hip)
         self.cdt = cdt
         wdt = L.torch_dtype(cdt)
         dev = self.device
         H = hidden
         self.state_dim, self.hidden, self.layers = state_dim, hidden, layers
         fpad, inpad = _pad_to(force_dim), _pad_to(H // 2 + state_dim)
-
-        def padk(w, k):
-            o = torch.zeros(w.shape[0], k)
-            o[:, : w.shape[1]] = w
-            return o
-
+        if H != 256:
+            raise L.VtError("LstmEngine: hidden_dim must be 256 (the persistent kernel's wave <-> hidden-unit deal)")
         g = lambda m, k: mods[m][k].detach().float().cpu()
-        W = [padk(g("force_encoder", "0.weight"), fpad).to(wdt).to(dev), g("force_encoder", "0.bias").to(dev),
-             g("force_encoder", "2.weight").to(wdt).to(dev), g("force_encoder", "2.bias").to(dev)]
+
+        def pack(w: torch.Tensor, row_starts, kpad: int) -> torch.Tensor:
+            """[N, K] -> MFMA fragment order [tile][k-step][lane][8]: element (lane, j) of (tile, ks) = w[row_starts[tile] + lane % 16]
+            [ks*32 + (lane // 16)*8 + j]; rows / columns beyond the matrix are zero.  A wave's load instruction then reads one
+            contiguous KiB (csrc/vt_lstm.hip)."""
+            N, K = w.shape
+            wp = torch.zeros(max(max(row_starts) + 16, N), kpad)
+            wp[:N, :K] = w
+            lane = torch.arange(64)
+            rows = torch.tensor(row_starts)[:, None] + (lane % 16)[None, :]                      # [tiles, 64]
+            cols = (torch.arange(kpad // 32) * 32)[:, None, None] + ((lane // 16) * 8)[None, :, None] + torch.arange(8)[None, None, :]   # [ks, 64, 8]
+            out = wp[rows[:, None, :, None], cols[None, :, :, :]]                                # [tiles, ks, 64, 8]
+            if cdt == L.F32X3:        # [tiles, ks, 64, (hi 8 | lo 8)] bf16: per lane 16 B of hi then 16 B of lo
+                hi = out.to(torch.bfloat16)
+                lo = (out - hi.float()).to(torch.bfloat16)
+                return torch.cat([hi, lo], dim=-1).contiguous().to(dev)
+            return out.contiguous().to(wdt).to(dev)
+
+        seq_tiles = lambda n: [16 * i for i in range(n // 16)]
+        gate_tiles = [q * 256 + 32 * w_ + 16 * t for w_ in range(8) for q in range(4) for t in range(2)]     # tile 8w + 2q + t
+        W = [pack(g("force_encoder", "0.weight"), seq_tiles(H // 2), 32), g("force_encoder", "0.bias").to(dev),
+             pack(g("force_encoder", "2.weight"), seq_tiles(H // 2), H // 2), g("force_encoder", "2.bias").to(dev)]
         for l in range(layers):
-            wih = g("lstm", f"weight_ih_l{l}")
-            W += [padk(wih, inpad if l == 0 else H).to(wdt).to(dev), g("lstm", f"weight_hh_l{l}").to(wdt).to(dev),
-                  g("lstm", f"bias_ih_l{l}").to(dev), g("lstm", f"bias_hh_l{l}").to(dev)]
-        W += [g("output_head", "0.weight").to(wdt).to(dev), g("output_head", "0.bias").to(dev),
+            wih, whh = g("lstm", f"weight_ih_l{l}"), g("lstm", f"weight_hh_l{l}")
+            kx = 160 if l == 0 else H
+            wcat = torch.zeros(4 * H, kx + H)
+            wcat[:, : wih.shape[1]] = wih
+            wcat[:, kx:] = whh
+            W += [pack(wcat, gate_tiles, kx + H), (g("lstm", f"bias_ih_l{l}") + g("lstm", f"bias_hh_l{l}")).to(dev)]
+        hb2 = torch.zeros(16)
+        hb2[:state_dim] = g("output_head", "4.bias")
+        W += [pack(g("output_head", "0.weight"), seq_tiles(H), 2 * H), g("output_head", "0.bias").to(dev),
               g("output_head", "1.weight").to(dev), g("output_head", "1.bias").to(dev),
-              g("output_head", "4.weight").to(wdt).to(dev), g("output_head", "4.bias").to(dev)]
+              pack(g("output_head", "4.weight"), [0], H), hb2.to(dev)]
         W = [w.contiguous() for w in W]
         self._weights = W
         desc = L.LstmDesc()
@@ -559,4 +580,19 @@ class LstmEngine:
         ws = self._ws.get(lib.vt_lstm_workspace_bytes(self._h, B))
         L.check(lib.vt_lstm_step(self._h, L.ptr(obs_cond), L.ptr(vla_n), L.ptr(force), L.ptr(h), L.ptr(c), L.ptr(out), B, L.ptr(ws),
                                  L.stream_ptr(dev)), "vt_lstm_step")
+        return out
+
+    def sequence(self, obs_cond, vla_n, force, h, c) -> torch.Tensor:
+        """T ticks in ONE kernel launch: vla_n [B,T,S], force [B,T,F]; h, c [layers,B,H] fp32 updated in place -> [B,T,S]."""
+        dev = self.device
+        B, T, _ = vla_n.shape
+        obs_cond = obs_cond.to(dev, torch.float32).contiguous()
+        vla_n = vla_n.to(dev, torch.float32).contiguous()
+        force = force.to(dev, torch.float32).contiguous()
+        if tuple(force.shape[:2]) != (B, T) or obs_cond.shape != (B, self.hidden):
+            raise ValueError(f"LstmEngine.sequence: obs_cond {tuple(obs_cond.shape)} / force {tuple(force.shape)} do not match vla {tuple(vla_n.shape)}")
+        assert h.is_contiguous() and c.is_contiguous() and h.dtype == torch.float32 and tuple(h.shape) == (self.layers, B, self.hidden)
+        out = torch.empty(B, T, self.state_dim, dtype=torch.float32, device=dev)
+        L.check(L.lib().vt_lstm_sequence(self._h, L.ptr(obs_cond), L.ptr(vla_n), L.ptr(force), L.ptr(h), L.ptr(c), L.ptr(out), B, T,
+                                         L.stream_ptr(dev)), "vt_lstm_sequence")
         return out
