@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dino", default="base", choices=["small", "base"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm"],
+    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm", "marker"],
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
@@ -151,6 +151,15 @@ def main():
         lstm.to(dev)
         lstm.stats = {k: v.to(dev) for k, v in synth.unit_stats().items()}
         lstm_in = dict(forces=torch.randn(B, T, 3, device=dev))
+    mk = mk_frames = None
+    if args.workload == "marker":       # GelSight frames -> marker displacements + force estimate, a 256-frame stream per step
+        from residual_controller.tactile.marker.marker_tracker import EnhancedMarkerTracker
+        rngm = np.random.default_rng(77)
+        base_frames = [synth.synth_gel_frame(rngm, shift=(1.5 * np.sin(i), 1.0 * np.cos(i)), bulge=0.5 * i) for i in range(8)]
+        mk_frames = torch.from_numpy(np.stack([base_frames[i % 8] for i in range(8 * B)])).to(dev)       # [8B, 240, 320, 3] uint8
+        mk = EnhancedMarkerTracker(7, 9, device=dev)
+        mk.calibrate(base_frames[0])
+        args.no_graph = True                                                # the stream API returns host arrays (counts are read back)
     sig = sig_px = None
     if args.workload == "siglip":       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
         from vlatouch.engine import SiglipEngine
@@ -170,6 +179,9 @@ def main():
             return
         if args.workload == "siglip":
             out_holder["out"] = sig.forward(sig_px)
+            return
+        if args.workload == "marker":
+            out_holder["out"] = mk.track_frames(mk_frames)
             return
         if args.workload == "dino_mlp":
             out_holder["out"] = ctrl.encode_observation(inp["state"], inp["cam1"], inp["cam2"], inp["forces"])
@@ -268,7 +280,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    total_chunks = B * world * args.steps
+    total_chunks = B * world * args.steps * (8 if args.workload == "marker" else 1)
     value = total_chunks / elapsed
 
     WL = {
@@ -284,12 +296,14 @@ def main():
                  "%d sequential ticks of force MLP -> 2-layer LSTM -> residual head per chunk" % (args.dino, args.res, T)),
         "siglip": ("chunks' worth of image tokens/sec (6 frames per chunk)", "siglip (SURVEY 8f-1): SigLIP-so400m-patch14-384 tower, 6 x 384x384 frames per "
                    "chunk -> 6 x 729 x 1152 image tokens, batch %d chunks (%d images per step)" % (B, 6 * B)),
+        "marker": ("GelSight frames/sec (marker displacements + force estimate m_t)", "marker (SURVEY 8f-3): %d frames of 240x320x3 per step: blur -> adaptive "
+                   "threshold -> open -> components -> contour centroids -> nearest-baseline displacement -> force; value counts FRAMES" % (8 * B)),
         "rdt": ("RDT-1B action chunks/sec", "rdt = BASELINE configs[2] shape: RDT-1B, %d-step DPM-Solver++, cached T5-sized (4096-d) language "
                 "tokens, batch %d" % (args.rdt_steps, B)),
     }[args.workload]
     res = {
         "metric": WL[0],
-        "value": round(value, 2), "unit": "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(value, 2), "unit": "frames/s" if args.workload == "marker" else "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 4), "p50_step_latency_ms": round(p50, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
         "config": {

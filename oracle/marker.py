@@ -204,24 +204,8 @@ def estimate_force(displacement: np.ndarray) -> Tuple[float, np.ndarray]:
     return mag, (avg / mag if mag > 0 else np.zeros(2))
 
 
-def synth_gel_frame(rng: np.random.Generator, shift=(0.0, 0.0), bulge: float = 0.0, H: int = 240, W: int = 320, rows: int = 7, cols: int = 9) -> np.ndarray:
-    """A GelSight-like BGR frame: bright gel with an illumination gradient and sensor noise, a rows x cols grid of dark
-    round markers displaced by a rigid shift plus a radial bulge (contact)."""
-    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
-    base = 150 + 40 * (xx / W) - 30 * (yy / H)
-    img = np.stack([base * 0.9, base, base * 1.05], axis=-1)
-    gx = np.linspace(28, W - 28, cols)
-    gy = np.linspace(24, H - 24, rows)
-    cx0, cy0 = W / 2, H / 2
-    k = 0
-    for y in gy:
-        for x in gx:
-            r2 = ((x - cx0) ** 2 + (y - cy0) ** 2) / (cx0 ** 2 + cy0 ** 2)
-            px = x + shift[0] + bulge * (x - cx0) / cx0 * np.exp(-3 * r2)
-            py = y + shift[1] + bulge * (y - cy0) / cy0 * np.exp(-3 * r2)
-            d2 = (xx - px) ** 2 + 1.0 * (yy - py) ** 2 * (1.0 + 0.15 * ((k * 7) % 5 - 2) / 2)      # slightly elliptic, per-marker size
-            sig = 2.6 + 0.25 * ((k * 5) % 6)
-            img *= (1 - 0.75 * np.exp(-d2 / (2 * sig ** 2)))[..., None]
-            k += 1
-    img += rng.normal(0, 3.0, img.shape)
-    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+def synth_gel_frame(*args, **kw) -> np.ndarray:
+    """The synthetic GelSight frame generator lives with the other synthetic inputs (vlatouch/synth.py); kept here as an alias for
+    the golden-vector script and the tests."""
+    from vlatouch import synth
+    return synth.synth_gel_frame(*args, **kw)

@@ -16,7 +16,7 @@ import types
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vla-touch_amd")]
 from oracle import marker as M  # noqa: E402
 
 REF = "/root/reference/VLA/residual_controller/tactile/marker/marker_tracker.py"
