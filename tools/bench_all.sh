@@ -1,0 +1,21 @@
+#!/bin/bash
+# every workload of bench.py once -> gpurun_out/rNN_bench_*.json (copy into profiles/)
+R=${1:-r02}; O=gpurun_out
+run() { name=$1; shift; python bench.py "$@" > $O/${R}_bench_$name.json 2> $O/${R}_bench_$name.err; python - <<P
+import json
+try:
+    d=json.loads(open("$O/${R}_bench_$name.json").read().strip().splitlines()[-1]); print("$name", d["value"], d["unit"], d["ms_per_step"], "p50", d["p50_step_latency_ms"])
+except Exception as e: print("$name FAILED", e)
+P
+}
+run full_n1
+run full_streams1_n1 --streams 1 --no-cpu-baseline
+run pi_refine_n1 --workload pi_refine --no-cpu-baseline
+run pi_refine_streams1_n1 --workload pi_refine --no-cpu-baseline --streams 1
+run dino_mlp_n1 --workload dino_mlp --no-cpu-baseline
+run rdt_n1 --workload rdt --no-cpu-baseline
+run rdt50_b16_n1 --workload rdt --rdt-steps 50 --batch 16 --steps 6 --warmup 1 --no-cpu-baseline
+run siglip_n1 --workload siglip --no-cpu-baseline --steps 6 --warmup 1
+run lstm_n1 --workload lstm --no-cpu-baseline
+run marker_n1 --workload marker --no-cpu-baseline
+run full_b1_n1 --batch 1 --streams 1 --no-cpu-baseline
