@@ -267,7 +267,7 @@ def main():
         # ---- roofline leg: one eager step with HIP events around every launch of the dominant GEMM kernel
         lib = L.lib()
         prof = {}
-        for mode in (2, 3):          # 2 = gemm_pp256_kernel, 3 = gemm_glds_kernel (separate eager steps: one event pool)
+        for mode in (2, 3, 4):       # 2 = 256-square GEMM tile, 3 = 160 / 128-column GEMM tiles, 4 = cached cross-attention (one eager step each)
             lib.vt_prof_enable(mode)
             step()
             stream.synchronize()
@@ -368,6 +368,17 @@ def main():
                    "RDT qkv projections, DINOv2 Linears)", "gemm_pp256")
     r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)",
                 "gemm_ppk")
+    r_at = None
+    if prof.get(4, (0, 0, 0, 0))[3] > 0 and prof[4][0] > 0:
+        ms_, fl_, by_, n_ = prof[4]
+        gbs = by_ / (ms_ * 1e-3) / 1e9
+        r_at = {"kernel": "attn_kvt_ring_kernel (RDT cross-attention against the cached condition K / Vt tile stream, re-read every denoise step)",
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+                "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
+                "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4),
+                "traffic": (round(pmc["attn_kvt"]["per_launch_bytes"] / 1e9, 4) if "attn_kvt" in pmc else None),
+                "traffic_unit": "GB per launch averaged over image- and language-layer calls (PMC 2*FETCH_SIZE + WRITE_SIZE)",
+                "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3)}
     if onbox is not None:
         res["onbox_peaks"] = onbox
         for r in (r_pp, r_gl):
@@ -375,8 +386,7 @@ def main():
                 r["frac_of_measured_gemm_peak"] = round(r["achieved"] / onbox["bf16_gemm_8192_tflops"], 4)
     if r_pp is not None:
         res["roofline"] = r_pp
-        if r_gl is not None:
-            res["roofline_other"] = [r_gl]
+        res["roofline_other"] = [r for r in (r_gl, r_at) if r is not None]
     elif r_gl is not None:
         res["roofline"] = r_gl
 

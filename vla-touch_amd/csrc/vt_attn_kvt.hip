@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include "vt_common.h"
 #include "vt_kernels.h"
+#include "vt_prof.h"
 
 namespace {
 
@@ -447,6 +448,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
     if (padded < best) { best = padded; nw = w; }
   }
   const int qblocks = (p.Nq + nw * 16 - 1) / (nw * 16);
+  // algorithmic work of one call: every (batch, head) streams its sample's K and Vt tiles once (16 KiB per 64 keys) + Q in, O out
+  const double kv_bytes = (double)p.B * p.H * (((long)p.Nk + 63) / 64) * 16384.0, qo_bytes = 2.0 * p.B * p.H * p.Nq * 64 * 2.0;
+  VtProfScope prof(4, 4.0 * p.B * p.H * (double)p.Nq * p.Nk * 64, kv_bytes + qo_bytes, s);
   // VLATOUCH_ATTN_RING: 0 = the 2-stage whole-tile kernel, 4 / 5 = half-tile ring with counted waits (default 5)
   static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
 #define VT_KVT_GO(grid) \

@@ -1,6 +1,7 @@
 // vt_prof.h — live per-launch timing of the LDS-DMA GEMM kernels (bench.py's roofline leg): while enabled, every launch of
 // the selected kernel class is bracketed by HIP events recorded on its launch stream.
-//   vt_prof_enable(0) off; (1) both classes; (2) only gemm_pp256_kernel (vt_gemm_pp.hip); (3) only gemm_glds_kernel (vt_gemm_fast.hip)
+//   vt_prof_enable(0) off; (1) both classes; (2) only gemm_pp256_kernel (vt_gemm_pp.hip); (3) only gemm_glds_kernel (vt_gemm_fast.hip);
+//   (4) only the cached cross-attention (vt_attn_kvt.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vt_common.h"
@@ -24,6 +25,14 @@ struct VtProfScope {
     while (g_vt_prof.created < 2 * (idx + 1)) (void)hipEventCreate(&g_vt_prof.ev[g_vt_prof.created++]);
     g_vt_prof.flops += 2.0 * p.M * (double)p.N * p.K * p.groups;
     g_vt_prof.bytes += ((double)p.M * p.K + (double)p.N * p.K) * 2.0 * p.groups + (double)p.M * p.N * p.groups * (p.c_dtype == VT_F32 ? 4.0 : 2.0);
+    (void)hipEventRecord(g_vt_prof.ev[2 * idx], s);
+  }
+  // a kernel that is not a GEMM: the caller states its algorithmic flops / bytes (class 4 = cached cross-attention, HBM-bound)
+  VtProfScope(int cls, double flops, double bytes, hipStream_t st) : active(g_vt_prof.on && g_vt_prof.mode == cls && g_vt_prof.used < VtProfState::MAXEV), s(st), idx(0) {
+    if (!active) return;
+    idx = g_vt_prof.used++;
+    while (g_vt_prof.created < 2 * (idx + 1)) (void)hipEventCreate(&g_vt_prof.ev[g_vt_prof.created++]);
+    g_vt_prof.flops += flops; g_vt_prof.bytes += bytes;
     (void)hipEventRecord(g_vt_prof.ev[2 * idx], s);
   }
   ~VtProfScope() { if (active) (void)hipEventRecord(g_vt_prof.ev[2 * idx + 1], s); }

@@ -6,6 +6,11 @@ This is the product's own statement of the published algorithm (Lu et al. 2022, 
 data-prediction form) with diffusers' defaults as the reference constructs it: solver_order 2, midpoint,
 lower_order_final, `linspace` timestep spacing, zero final sigma, no thresholding / Karras sigmas.  The update of
 step k is folded into three scalars,   x <- a_k x + b0_k x0_k + b1_k x0_{k-1},   applied by one fused kernel.
+
+bf16 note: the kernel evaluates the update in fp32 from the bf16 x0 and rounds the state to bf16 ONCE per step (the reference's
+`.to(dtype)`, rdt_runner.py:160).  That is what diffusers >= 0.28 does (it up-casts sample and model output to fp32 inside `step`);
+diffusers 0.27.2 — upstream RDT-1B's pin — keeps the intermediate products in bf16 (0-dim fp32 sigmas do not promote) and can differ
+by a few bf16 ulps per step.  Independent checks of the coefficients: tests/test_dpm_analytic.py.
 """
 from __future__ import annotations
 
