@@ -203,10 +203,12 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
  * Gaussian threshold (11, C = 2, inverted) -> 3x3 open -> outer contours of the 8-connected components -> polygon area in
  * (min_area, max_area) -> truncated polygon centroid, in cv2.findContours order (last found first).
  * markers [N][max_markers][2] int32 (x, y), counts [N] (may exceed max_markers or max_cand: overflow, the caller checks),
- * binary_out [N][H][W] bytes (0/1; the reference's `processed_frame` / 255) or NULL.  input_is_binary != 0: `frames` is
- * already a processed binary image [N][H][W] (non-zero = marker), only the contour stage runs (detect_markers :154). */
+ * binary_out [N][H][W] bytes (0/1; the reference's `processed_frame` / 255) or NULL.
+ * mode 0: gelsight_version 'standard' (init_standard).  mode 1: `frames` is already a processed binary image [N][H][W] (non-zero =
+ * marker), only the contour stage runs (detect_markers :154).  mode 2: 'HSR' (init_HSR :116-152: invert, equalizeHist, 5x5 blur,
+ * threshold > 50, 3x3 open). */
 size_t vt_marker_workspace_bytes(int N, int H, int W, int max_cand);
-int vt_marker_detect(const uint8_t* frames, int channels, int input_is_binary, int N, int H, int W, double min_area, double max_area,
+int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H, int W, double min_area, double max_area,
                      int max_cand, int* markers, int* counts, int max_markers, uint8_t* binary_out, void* workspace,
                      vt_stream_t stream);
 /* baseline [n_base][2] int32 -> disp [N][max_markers][2] int32 (marker - nearest baseline marker, ties to the lower index),

@@ -2,6 +2,7 @@
 
 Restates /root/reference/VLA/residual_controller/tactile/marker/marker_tracker.py:
   init_standard :81-114 (BGR2GRAY -> GaussianBlur 5x5 -> adaptiveThreshold(GAUSSIAN_C, BINARY_INV, 11, 2) -> MORPH_OPEN 3x3),
+  init_HSR :116-152 (BGR2GRAY -> invert -> equalizeHist -> GaussianBlur 5x5 -> threshold 50 -> MORPH_OPEN 3x3),
   detect_markers :154-241 (findContours EXTERNAL -> contourArea in (10, 500) -> contour moments -> int centroid),
   match_and_compute_displacement :308-341 (nearest baseline marker), estimate_force :343-373 (mean displacement, norm, direction).
 
@@ -174,6 +175,30 @@ def preprocess_standard(frame: np.ndarray) -> np.ndarray:
     """init_standard :81-114."""
     gray = bgr2gray(frame) if frame.ndim == 3 else frame
     return morph_open3(adaptive_threshold_gaussian_inv(gaussian_blur5_u8(gray), 11, 2))
+
+
+def equalize_hist(gray: np.ndarray) -> np.ndarray:
+    """cv::equalizeHist: lut[i] = saturate_cast<uchar>(cumsum over (first non-empty bin, i] * 255 / (total - hist[first])), float32
+    scale, round half to even; a constant image is returned unchanged."""
+    hist = np.bincount(gray.reshape(-1), minlength=256).astype(np.int64)
+    total = int(gray.size)
+    i0 = int(np.nonzero(hist)[0][0])
+    if hist[i0] == total:
+        return gray.copy()
+    scale = np.float32(255.0) / np.float32(total - hist[i0])
+    lut = np.zeros(256, dtype=np.uint8)
+    s = 0
+    for i in range(i0 + 1, 256):
+        s += int(hist[i])
+        lut[i] = np.uint8(min(255, max(0, int(np.rint(np.float32(s) * scale)))))
+    return lut[gray]
+
+
+def preprocess_hsr(frame: np.ndarray) -> np.ndarray:
+    """init_HSR :116-152: gray -> 255 - gray -> equalizeHist -> GaussianBlur 5x5 -> threshold(> 50) -> MORPH_OPEN 3x3."""
+    gray = bgr2gray(frame) if frame.ndim == 3 else frame
+    eq = equalize_hist((255 - gray.astype(np.int32)).astype(np.uint8))
+    return morph_open3(np.where(gaussian_blur5_u8(eq) > 50, 255, 0).astype(np.uint8))
 
 
 def detect_markers(processed: np.ndarray, min_area: float = 10, max_area: float = 500) -> np.ndarray:

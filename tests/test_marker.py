@@ -10,7 +10,7 @@ import torch
 
 from tests import cases
 from oracle import marker as M
-from tools.make_golden_marker import frames as golden_frames, MOTION
+from tools.make_golden_marker import frames as golden_frames, hsr_frames, MOTION
 
 
 def G():
@@ -34,6 +34,22 @@ def test_oracle_matches_reference_class_outputs():
     for i, ((sx, sy), bulge) in enumerate(MOTION):
         mean = g[f"disp_{i}"].mean(0)
         assert abs(mean[0] - sx) < 1.0 and abs(mean[1] - sy) < 1.0, (i, mean)
+
+
+def test_oracle_hsr_matches_reference_class_outputs():
+    g, fr = G(), hsr_frames()
+    base = M.detect_markers(M.preprocess_hsr(fr[0]))
+    assert np.array_equal(base, g["hsr_baseline"]) and len(base) == 63
+    for i, f in enumerate(fr):
+        proc = M.preprocess_hsr(f)
+        assert int(proc.astype(np.int64).sum()) == int(g[f"hsr_binary_sum_{i}"])
+        cur = M.detect_markers(proc)
+        assert np.array_equal(cur, g[f"hsr_markers_{i}"])
+        assert np.array_equal(M.match_displacement(cur, base), g[f"hsr_disp_{i}"])
+    # equalizeHist known answers: a constant image is unchanged; two equal-population levels map to 0 and 255
+    assert (M.equalize_hist(np.full((4, 4), 9, np.uint8)) == 9).all()
+    two = np.array([[10, 10, 200, 200]], np.uint8)
+    assert M.equalize_hist(two).tolist() == [[0, 0, 255, 255]]
 
 
 def test_oracle_primitives_known_answers():
@@ -87,6 +103,23 @@ def test_device_tracker_matches_reference_golden():
 
 
 @gpu
+def test_device_tracker_hsr_matches_reference_golden():
+    from residual_controller.tactile.marker.marker_tracker import EnhancedMarkerTracker
+    g, fr = G(), hsr_frames()
+    tr = EnhancedMarkerTracker(grid_rows=7, grid_cols=9, gelsight_version='HSR', device="cuda:0")
+    assert np.array_equal(tr.calibrate(fr[0]), g["hsr_baseline"])
+    for i, f in enumerate(fr):
+        proc = tr.preprocess_frame(f)
+        assert int(proc.astype(np.int64).sum()) == int(g[f"hsr_binary_sum_{i}"]) and np.array_equal(proc, M.preprocess_hsr(f))
+        assert np.array_equal(tr.detect_markers(proc), g[f"hsr_markers_{i}"])
+        assert np.array_equal(tr.get_marker_state(f), g[f"hsr_disp_{i}"])
+    tr2 = EnhancedMarkerTracker(grid_rows=7, grid_cols=9, gelsight_version='HSR', device="cuda:0")
+    disp, mag, _ = tr2.track_frames(np.stack(fr))
+    for i in range(len(fr)):
+        assert np.array_equal(disp[i, :int(tr2.last_counts[i])], g[f"hsr_disp_{i}"])
+
+
+@gpu
 def test_device_tracker_batched_stream_equals_frame_by_frame():
     g, fr = G(), golden_frames()
     tr = tracker()
@@ -130,9 +163,13 @@ def test_device_tracker_vs_oracle_random_blobs_and_edges(H, W):
     tr2 = tracker()
     with pytest.raises(ValueError):
         tr2.preprocess_frame(frames[0].astype(np.float32))
+    # the HSR variant on arbitrary frames (incl. its degenerate "whole gel is foreground" outcome) == the oracle
     tr2.gelsight_version = "HSR"
-    with pytest.raises(NotImplementedError):
-        tr2.preprocess_frame(frames[0])
+    tr2.expected_markers = 10 ** 6
+    for f in (frames[0], frames[3], np.full((H, W, 3), 77, np.uint8)):
+        ref = M.preprocess_hsr(f)
+        assert np.array_equal(tr2.preprocess_frame(f), ref)
+        assert np.array_equal(np.asarray(tr2.detect_markers(tr2.preprocess_frame(f))).reshape(-1, 2), M.detect_markers(ref))
 
 
 @gpu

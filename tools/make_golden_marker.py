@@ -29,6 +29,25 @@ def frames():
     return [M.synth_gel_frame(rng, shift=s, bulge=b) for s, b in MOTION]
 
 
+def hsr_frames():
+    """Frames for the HSR variant (init_HSR inverts, equalises the histogram and thresholds at 50): a UNIFORM bright gel — the one
+    background histogram equalisation maps to 0 — with dark markers of varied depth, noise-free; rigid shifts between frames."""
+    out = []
+    H, W = 240, 320
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float64)
+    for (sx, sy), _ in MOTION[:4]:
+        img = np.full((H, W), 200.0)
+        k = 0
+        for y in np.linspace(24, H - 24, 7):
+            for x in np.linspace(28, W - 28, 9):
+                d2 = (xx - x - sx) ** 2 + (yy - y - sy) ** 2
+                img *= 1 - (0.55 + 0.04 * (k % 7)) * np.exp(-d2 / (2 * (2.4 + 0.2 * (k % 5)) ** 2))
+                k += 1
+        g = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+        out.append(np.stack([g, g, g], axis=-1))
+    return out
+
+
 def cv2_standin():
     cv2 = types.ModuleType("cv2")
     cv2.COLOR_BGR2GRAY, cv2.ADAPTIVE_THRESH_GAUSSIAN_C, cv2.THRESH_BINARY_INV, cv2.THRESH_BINARY = 6, 1, 1, 0
@@ -46,6 +65,13 @@ def cv2_standin():
         assert maxval == 255 and method == cv2.ADAPTIVE_THRESH_GAUSSIAN_C and ttype == cv2.THRESH_BINARY_INV
         return M.adaptive_threshold_gaussian_inv(img, block, C)
 
+    def equalizeHist(img):
+        return M.equalize_hist(img)
+
+    def threshold(img, thresh, maxval, ttype):
+        assert ttype == cv2.THRESH_BINARY and maxval == 255
+        return thresh, np.where(img > thresh, 255, 0).astype(np.uint8)
+
     def morphologyEx(img, op, kernel):
         assert op == cv2.MORPH_OPEN and kernel.shape == (3, 3) and kernel.all()
         return M.morph_open3(img)
@@ -61,7 +87,7 @@ def cv2_standin():
         m00, m10, m01 = M.contour_moments(c.reshape(-1, 2))
         return {"m00": m00, "m10": m10, "m01": m01}
 
-    for f in (cvtColor, GaussianBlur, adaptiveThreshold, morphologyEx, findContours, contourArea, moments):
+    for f in (cvtColor, GaussianBlur, adaptiveThreshold, morphologyEx, findContours, contourArea, moments, equalizeHist, threshold):
         setattr(cv2, f.__name__, f)
     return cv2
 
@@ -91,6 +117,17 @@ def main():
         out[f"disp_{i}"] = np.asarray(disp)
         out[f"force_{i}"] = np.array([mag, direction[0], direction[1]], dtype=np.float64)
         print(i, len(cur), mag, direction)
+    # the 'HSR' sensor variant (init_HSR): dark gel, bright markers (its inversion + equalisation + fixed threshold expect that)
+    hf = hsr_frames()
+    th = mod.EnhancedMarkerTracker(grid_rows=7, grid_cols=9, gelsight_version='HSR')
+    out["hsr_baseline"] = np.asarray(th.calibrate(hf[0]))
+    for i, f in enumerate(hf):
+        proc = th.preprocess_frame(f)
+        out[f"hsr_binary_sum_{i}"] = np.int64(proc.astype(np.int64).sum())
+        out[f"hsr_markers_{i}"] = np.asarray(th.detect_markers(proc))
+        disp = th.get_marker_state(f)
+        out[f"hsr_disp_{i}"] = np.asarray(disp)
+        print("HSR", i, len(out[f"hsr_markers_{i}"]), th.estimate_force(disp)[0])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "g12_marker.npz"), **out)
 
 

@@ -39,8 +39,46 @@ __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n
 
 struct MeanKernel { float k[11]; };
 
+// gray value of pixel (y, x) of a frame: BGR -> gray fixed point, or the single channel
+__device__ __forceinline__ int gray_at(const uint8_t* F, int channels, int W, int y, int x) {
+  const uint8_t* px = F + ((size_t)y * W + x) * channels;
+  return channels == 3 ? ((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14) : px[0];
+}
+
+// 'HSR' sensor (init_HSR): histogram of the INVERTED gray image, one block per (frame, slab of rows)
+__global__ __launch_bounds__(256) void marker_hist_kernel(const uint8_t* __restrict__ frames, int channels, int H, int W, int* __restrict__ hist) {
+  __shared__ int h[256];
+  h[threadIdx.x] = 0;
+  __syncthreads();
+  const uint8_t* F = frames + (size_t)blockIdx.y * H * W * channels;
+  const int n = H * W;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&h[255 - gray_at(F, channels, W, i / W, i % W)], 1);
+  __syncthreads();
+  if (h[threadIdx.x]) atomicAdd(&hist[blockIdx.y * 256 + threadIdx.x], h[threadIdx.x]);      // integer adds: order-independent
+}
+// cv::equalizeHist look-up table per frame (256 entries; a constant image maps to itself)
+__global__ void marker_lut_kernel(const int* __restrict__ hist, int total, uint8_t* __restrict__ lut) {
+  if (threadIdx.x != 0) return;
+  const int* h = hist + blockIdx.x * 256;
+  uint8_t* l = lut + blockIdx.x * 256;
+  int i0 = 0;
+  while (i0 < 255 && h[i0] == 0) ++i0;
+  for (int i = 0; i < 256; ++i) l[i] = 0;
+  if (h[i0] == total) { l[i0] = (uint8_t)i0; return; }
+  const float scale = 255.0f / (float)(total - h[i0]);
+  int sum = 0;
+  for (int i = i0 + 1; i < 256; ++i) {
+    sum += h[i];
+    int v = (int)rintf(__fmul_rn((float)sum, scale));
+    l[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
+// HSR = false: init_standard (adaptive Gaussian threshold of the blurred gray image); HSR = true: init_HSR (gray -> 255 - gray ->
+// equalisation LUT -> blur -> fixed threshold > 50).  Same tile / halo plan for both.
+template <bool HSR>
 __global__ __launch_bounds__(256) void marker_binary_kernel(const uint8_t* __restrict__ frames, int channels, int H, int W, MeanKernel mk,
-                                                            uint8_t* __restrict__ binary) {
+                                                            const uint8_t* __restrict__ lut, uint8_t* __restrict__ binary) {
   __shared__ uint8_t gray[GW][GW + 2];
   __shared__ uint8_t blur[BW][BW + 2];
   __shared__ float hmean[BW][MW + 1];
@@ -53,8 +91,8 @@ __global__ __launch_bounds__(256) void marker_binary_kernel(const uint8_t* __res
   for (int e = tid; e < GW * GW; e += 256) {
     const int r = e / GW, c = e - r * GW;
     const int y = reflect101(y0 - HALO + r, H), x = reflect101(x0 - HALO + c, W);
-    const uint8_t* px = F + ((size_t)y * W + x) * channels;
-    gray[r][c] = channels == 3 ? (uint8_t)((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14) : px[0];
+    const int gv = gray_at(F, channels, W, y, x);
+    gray[r][c] = HSR ? lut[blockIdx.z * 256 + 255 - gv] : (uint8_t)gv;
   }
   __syncthreads();
   // ---- blurred tile (halo 7): position (r, c) <-> image (y0 - 7 + r, x0 - 7 + c); outside the image the adaptive mean sees the
@@ -74,6 +112,7 @@ __global__ __launch_bounds__(256) void marker_binary_kernel(const uint8_t* __res
   }
   __syncthreads();
   // ---- adaptive mean, horizontal pass: hmean (r, c) <-> image row y0 - 7 + r, column x0 - 2 + c
+  if (!HSR)
   for (int e = tid; e < BW * MW; e += 256) {
     const int r = e / MW, c = e - r * MW;
     float h = 0.f;
@@ -86,12 +125,16 @@ __global__ __launch_bounds__(256) void marker_binary_kernel(const uint8_t* __res
   for (int e = tid; e < MW * MW; e += 256) {
     const int r = e / MW, c = e - r * MW;
     const int y = y0 - 2 + r, x = x0 - 2 + c;
+    const bool inside = y >= 0 && y < H && x >= 0 && x < W;
+    if (HSR) {
+      thr[r][c] = !inside ? 2 : (blur[r + 5][c + 5] > 50 ? 1 : 0);
+      continue;
+    }
     float v = 0.f;
 #pragma unroll
     for (int i = 0; i < 11; ++i) v = __fadd_rn(v, __fmul_rn(mk.k[i], hmean[r + i][c]));
     int mean = (int)rintf(v);
     mean = mean < 0 ? 0 : (mean > 255 ? 255 : mean);
-    const bool inside = y >= 0 && y < H && x >= 0 && x < W;
     thr[r][c] = !inside ? 2 : (((int)blur[r + 5][c + 5] - mean <= -2) ? 1 : 0);       // 2 = outside the image
   }
   __syncthreads();
@@ -262,12 +305,15 @@ __global__ __launch_bounds__(64) void marker_disp_kernel(const int* __restrict__
 static size_t al256(size_t b) { return (b + 255) / 256 * 256; }
 size_t vt_marker_workspace_bytes(int N, int H, int W, int max_cand) {
   if (N < 1 || H < 1 || W < 1 || max_cand < 1) return 0;
-  return al256((size_t)N * H * W) + al256((size_t)N * H * W * 4) + al256((size_t)N * max_cand * sizeof(Cand)) + al256((size_t)N * 4);
+  return al256((size_t)N * H * W) + al256((size_t)N * H * W * 4) + al256((size_t)N * max_cand * sizeof(Cand)) + al256((size_t)N * 4) +
+         al256((size_t)N * 256 * 4) + al256((size_t)N * 256);      // + HSR histogram and equalisation table
 }
 
-int vt_marker_detect(const uint8_t* frames, int channels, int input_is_binary, int N, int H, int W, double min_area, double max_area, int max_cand,
+int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H, int W, double min_area, double max_area, int max_cand,
                      int* markers, int* counts, int max_markers, uint8_t* binary_out, void* workspace, vt_stream_t stream) {
   if (!frames || !markers || !counts || !workspace) return vt_fail(VT_ERR_ARG, "vt_marker_detect: null argument");
+  const int input_is_binary = mode == 1;
+  if (mode < 0 || mode > 2) return vt_fail(VT_ERR_ARG, "vt_marker_detect: mode 0 (standard), 1 (binary input) or 2 (HSR)");
   if (input_is_binary && channels != 1) return vt_fail(VT_ERR_ARG, "vt_marker_detect: a binary input has one channel");
   if ((channels != 1 && channels != 3) || N < 1 || H < 5 || W < 5 || max_cand < 1 || max_markers < 1 || (long)H * W >= (1L << 30))
     return vt_fail(VT_ERR_ARG, "vt_marker_detect: bad shape (channels 1|3, H, W >= 5)");
@@ -276,14 +322,21 @@ int vt_marker_detect(const uint8_t* frames, int channels, int input_is_binary, i
   uint8_t* binary = (uint8_t*)ws; ws += al256((size_t)N * H * W);
   int* labels = (int*)ws; ws += al256((size_t)N * H * W * 4);
   Cand* cand = (Cand*)ws; ws += al256((size_t)N * max_cand * sizeof(Cand));
-  int* ncand = (int*)ws;
+  int* ncand = (int*)ws; ws += al256((size_t)N * 4);
+  int* hist = (int*)ws; ws += al256((size_t)N * 256 * 4);
+  uint8_t* lut = (uint8_t*)ws;
   const int HW = H * W;
   // cv::getGaussianKernel(11, sigma <= 0): sigma = 0.3*((11-1)*0.5-1)+0.8 = 2.0, float32 taps
   MeanKernel mk;
   { double k[11], sum = 0; for (int i = 0; i < 11; ++i) { const double x = i - 5.0; k[i] = exp(-(x * x) / (2.0 * 2.0 * 2.0)); sum += k[i]; }
     for (int i = 0; i < 11; ++i) mk.k[i] = (float)(k[i] / sum); }
   if (input_is_binary) hipLaunchKernelGGL(marker_nonzero_kernel, dim3((unsigned)(((long)N * HW + 255) / 256)), dim3(256), 0, s, frames, binary, (long)N * HW);
-  else hipLaunchKernelGGL(marker_binary_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, channels, H, W, mk, binary);
+  else if (mode == 2) {
+    if (hipMemsetAsync(hist, 0, (size_t)N * 256 * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "vt_marker_detect: memset");
+    hipLaunchKernelGGL(marker_hist_kernel, dim3(32, N), dim3(256), 0, s, frames, channels, H, W, hist);
+    hipLaunchKernelGGL(marker_lut_kernel, dim3(N), dim3(64), 0, s, (const int*)hist, HW, lut);
+    hipLaunchKernelGGL(marker_binary_kernel<true>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, channels, H, W, mk, (const uint8_t*)lut, binary);
+  } else hipLaunchKernelGGL(marker_binary_kernel<false>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, channels, H, W, mk, (const uint8_t*)nullptr, binary);
   hipLaunchKernelGGL(marker_label_local_init_kernel, dim3((HW + 255) / 256, N), dim3(256), 0, s, (const uint8_t*)binary, labels, HW);
   hipLaunchKernelGGL(marker_label_merge_kernel, dim3((HW + 255) / 256, N), dim3(256), 0, s, (const uint8_t*)binary, labels, H, W);
   if (hipMemsetAsync(ncand, 0, (size_t)N * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "vt_marker_detect: memset");

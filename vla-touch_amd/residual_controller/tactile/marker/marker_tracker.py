@@ -10,9 +10,9 @@ vt_marker_detect / vt_marker_displacement); there is no cv2 and no CPU path.
 MI355X-first addition: `track_frames(frames[N, H, W, 3])` labels a whole GelSight stream (an episode) in one batched call —
 the reference walks it frame by frame (`process_image_sequence`, :376-450).
 
-Kept on the host, as in the reference: the KMeans refinement when MORE than `expected_markers` blobs survive the area filter
-(:205-229, sklearn, a rare branch on a handful of points) and `filter_coords`.  Not implemented: the 'HSR' sensor variant
-(`init_HSR`, :116-152) -> NotImplementedError.
+Both sensor variants run on the device: 'standard' (`init_standard`, :81-114) and 'HSR' (`init_HSR`, :116-152: invert, histogram
+equalisation, blur, fixed threshold).  Kept on the host, as in the reference: the KMeans refinement when MORE than
+`expected_markers` blobs survive the area filter (:205-229, sklearn, a rare branch on a handful of points) and `filter_coords`.
 """
 from __future__ import annotations
 
@@ -63,7 +63,8 @@ class EnhancedMarkerTracker:
         binary = torch.empty(N, H, W, dtype=torch.uint8, device=self.device) if want_binary else None
         lib = L.lib()
         ws = self._ws.get(lib.vt_marker_workspace_bytes(N, H, W, MAX_CAND))
-        L.check(lib.vt_marker_detect(L.ptr(frames), Cc, int(is_binary), N, H, W, float(min_area), float(max_area), MAX_CAND, L.ptr(markers), L.ptr(counts),
+        mode = 1 if is_binary else (2 if self.gelsight_version == 'HSR' else 0)
+        L.check(lib.vt_marker_detect(L.ptr(frames), Cc, mode, N, H, W, float(min_area), float(max_area), MAX_CAND, L.ptr(markers), L.ptr(counts),
                                      max_markers, L.ptr(binary), L.ptr(ws), L.stream_ptr(self.device)), "vt_marker_detect")
         return markers, counts, binary
 
@@ -112,8 +113,6 @@ class EnhancedMarkerTracker:
     def preprocess_frame(self, frame):
         """-> the binary `processed_frame` (uint8 0/255 numpy, like cv2) of one frame.  The reference's two-call protocol
         (`detect_markers(preprocess_frame(frame))`) is kept by remembering the centroids computed in the same device pass."""
-        if self.gelsight_version == 'HSR':
-            raise NotImplementedError("gelsight_version='HSR' (init_HSR) is not implemented on the device path")
         t = self._frames(frame)
         markers, counts, binary = self._detect(t, want_binary=True)
         n = int(counts[0])
