@@ -35,6 +35,16 @@ def test_library_exports_every_declared_symbol():
     assert lib.vt_last_error() is not None
 
 
+def test_lzf_library_exports_its_header():
+    import ctypes as C
+    hdr = open(os.path.join(ROOT, "include", "vtlzf.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(vt_lzf_[a-z0-9_]+)\s*\(", hdr)))
+    assert syms == ["vt_lzf_compress", "vt_lzf_decompress"]
+    lib = C.CDLL(os.path.join(ROOT, "vla-touch_amd", "vlatouch", "libvtlzf.so"))
+    assert all(hasattr(lib, s) for s in syms)
+
+
 def test_ctypes_structs_match_c_layout():
     """sizeof/offsets of the parameter blocks, computed by compiling a tiny C++ probe against the real headers."""
     import ctypes as C

@@ -246,3 +246,35 @@ def test_predict_and_rdt_chunk_are_graph_capturable(controllers):
         g2.replay()
         stream.synchronize()
     assert torch.equal(holder["rdt"], eager)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-5), ("x3", 1e-4), ("bf16", 3e-2)])
+@pytest.mark.parametrize("B,T", [(1, 1), (19, 5), (33, 16)])
+def test_lstm_persistent_kernel_ragged_batches_vs_oracle(prec, tol, B, T):
+    """The one-launch LSTM head (csrc/vt_lstm.hip) on batch sizes that are not multiples of its 16-row blocks (1, 19, 33 rows), a single
+    tick and a 16-tick chunk, in its three arithmetic modes, against the oracle's step loop; T ticks in one launch == T one-tick
+    launches with the carried state, bit for bit (lstm_step_controller.py:232-319)."""
+    from oracle import controller as oc
+    from vlatouch.engine import LstmEngine
+    mods = cases.lstm_mods(384)
+    eng = LstmEngine({k: mods[k] for k in ("force_encoder", "lstm", "output_head")}, precision=prec, device="cuda:0")
+    g = synth_rng = __import__("vlatouch.synth", fromlist=["x"]).inputs_rng(40 + B)
+    obs = cases.T(g.standard_normal((B, 256), dtype=np.float32))
+    vla = cases.T(g.uniform(-1, 1, (B, T, 10)).astype(np.float32))
+    force = cases.T(g.standard_normal((B, T, 3), dtype=np.float32))
+    h0 = cases.T(0.1 * g.standard_normal((2, B, 256), dtype=np.float32))
+    c0 = cases.T(0.1 * g.standard_normal((2, B, 256), dtype=np.float32))
+    h, c = h0.cuda().clone(), c0.cuda().clone()
+    out = eng.sequence(obs, vla, force, h, c)
+    rh, rc, ref = h0.clone(), c0.clone(), []
+    for t in range(T):
+        o, rh, rc = oc.lstm_step(mods, obs, vla[:, t], force[:, t], rh, rc, 2)
+        ref.append(o)
+    ref = torch.stack(ref, dim=1)
+    assert out.shape == (B, T, 10)
+    assert err(out, ref.numpy()) < tol and err(h, rh.numpy()) < tol and err(c, rc.numpy()) < tol, (err(out, ref.numpy()), err(h, rh.numpy()))
+    h2, c2 = h0.cuda().clone(), c0.cuda().clone()
+    steps = torch.stack([eng.step(obs, vla[:, t], force[:, t], h2, c2) for t in range(T)], dim=1)
+    assert torch.equal(steps, out) and torch.equal(h2, h) and torch.equal(c2, c)
+    with pytest.raises(ValueError):
+        eng.sequence(obs[:-1] if B > 1 else obs.repeat(2, 1), vla, force, h, c)

@@ -7,6 +7,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string.h>
+#include "../../include/vtlzf.h"
 
 long vt_lzf_decompress(const uint8_t* in, long in_len, uint8_t* out, long out_len) {
   long ip = 0, op = 0;
