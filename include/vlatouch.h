@@ -216,6 +216,35 @@ int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H
 int vt_marker_displacement(const int* markers, const int* counts, int N, int max_markers, const int* baseline, int n_base,
                            int* disp, double* force, vt_stream_t stream);
 
+/* ---------------------------------------------------------------- controller training step primitives
+ * Replace torch autograd / optim.AdamW / torch_ema around the interpolant losses (bridge/bridge_model.py:183-246 velocity_loss,
+ * score_loss, b_loss, get_loss; bridge_train.py:49-58, 312-334).  fp32, channel-last [B][T][C]; the matrix products of the backward pass
+ * are vt_gemm calls on the buffers these produce (vlatouch/train.py composes them; csrc/vt_train.hip). */
+/* out[(tap*Cin + ci)][b*Tout + t] = x[b][t*stride + off0 + tap][ci] (0 outside): transposed im2col, the operand of a weight gradient */
+int vt_im2col_t(const float* x, float* out, int B, int Tin, int Tout, int Cin, int taps, int stride, int off0, vt_stream_t stream);
+int vt_transpose(const float* in, float* out, int M, int N, vt_stream_t stream);                 /* [M][N] -> [N][M] */
+int vt_zero_stuff(const float* x, float* out, int B, int T, int C, vt_stream_t stream);           /* out[b][2u] = x[b][u], odd rows 0 */
+int vt_wflip(const float* W, float* WT, int Cout, int taps, int Cin, vt_stream_t stream);         /* [Cout][taps][Cin] -> [Cin][taps reversed][Cout] */
+int vt_colsum(const float* x, long ld, float* out, int M, int N, int accumulate, vt_stream_t stream);
+int vt_add_(float* a, const float* b, long n, vt_stream_t stream);
+int vt_copy_cols(const float* src, long lds, int off, float* dst, long ldd, int doff, int rows, int cols, int accumulate, vt_stream_t stream);
+int vt_mish(const float* x, const float* dy, float* out, long n, vt_stream_t stream);             /* dy NULL: mish(x); else dy * mish'(x) */
+/* backward of out = film_scale * mish(GroupNorm(c)) + film_bias: c, dout, dc [B*T][C]; film, dfilm [B][2C] (scale | bias) or NULL;
+ * dgamma_part, dbeta_part [B][C] per-sample partials (sum over B with vt_colsum). */
+int vt_gn_mish_bwd(const float* c, const float* gamma, const float* beta, const float* film, const float* dout, float* dc,
+                   float* dgamma_part, float* dbeta_part, float* dfilm, int B, int T, int C, int ngroups, float eps, vt_stream_t stream);
+int vt_gelu(const float* x, const float* dy, float* out, long n, vt_stream_t stream);             /* erf GELU / its backward */
+/* q_sample + the three loss targets of the LINEAR interpolant (bridge_model.py:103-107, 183-217, 248-258): xt, target_v = x1 - x0,
+ * target_s = -z, target_b = (x1 - x0) + gamma'(t) z, t_clipped[B]; z already scaled by beta_max; gamma_type as vt_si_sample. */
+int vt_si_qsample(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s,
+                  float* target_b, float* t_clipped, int B, long per_sample, int gamma_type, float t_min, vt_stream_t stream);
+/* loss[0] = mean_b(0.5 |out_b|^2 - <target_b, out_b>), dout = (out - target) / B   (the three interpolant losses share this form) */
+int vt_si_loss(const float* out, const float* target, float* dout, float* loss, int B, long per_sample, vt_stream_t stream);
+int vt_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+             int step, vt_stream_t stream);
+int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_t stream);
+int vt_posemb(const float* t, float* out, int B, int dim, vt_stream_t stream);                    /* SinusoidalPosEmb: [sin | cos] */
+
 #ifdef __cplusplus
 }
 #endif

@@ -148,6 +148,21 @@ SIGNATURES = {
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vt_rdt_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
+    "vt_im2col_t": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "vt_transpose": (_I, [_P, _P, _I, _I, _P]),
+    "vt_zero_stuff": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vt_wflip": (_I, [_P, _P, _I, _I, _I, _P]),
+    "vt_colsum": (_I, [_P, _L, _P, _I, _I, _I, _P]),
+    "vt_add_": (_I, [_P, _P, _L, _P]),
+    "vt_copy_cols": (_I, [_P, _L, _I, _P, _L, _I, _I, _I, _I, _P]),
+    "vt_mish": (_I, [_P, _P, _P, _L, _P]),
+    "vt_gn_mish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
+    "vt_gelu": (_I, [_P, _P, _P, _L, _P]),
+    "vt_si_qsample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _P]),
+    "vt_si_loss": (_I, [_P, _P, _P, _P, _I, _L, _P]),
+    "vt_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "vt_ema_update": (_I, [_P, _P, _L, _F, _P]),
+    "vt_posemb": (_I, [_P, _P, _I, _I, _P]),
     "vt_marker_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vt_marker_detect": (_I, [_P, _I, _I, _I, _I, _I, C.c_double, C.c_double, _I, _P, _P, _I, _P, _P, _P]),
     "vt_marker_displacement": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P]),

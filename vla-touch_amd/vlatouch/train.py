@@ -1,0 +1,536 @@
+"""Training step of the interpolant controller on the MI355X.
+
+Replaces, for one optimisation step, what the reference does with torch autograd:
+  * `StochasticInterpolants.get_loss` = velocity_loss + score_loss + b_loss over the three conditional 1-D U-Nets
+    (VLA/residual_controller/bridge/bridge_model.py:183-258) — q_sample, the three forwards, the three losses;
+  * `total_loss.backward()` through the U-Nets (bridge/networks/conditional_unet_1D.py:58-247) and, through `obs_cond`, the
+    state/force observation MLP (bridge_controller.py:42-48; the DINOv2 features are inputs, frozen);
+  * `optim.AdamW(net.parameters() + state_encoder.parameters()).step()` and `ema.update()` (bridge_train.py:49-58, 312-334).
+
+Design: fp32 master weights live on the device in the PACKED layouts the kernels consume (conv weights tap-major [Cout][k*Cin],
+ConvTranspose1d as its equivalent stride-1 convolution over a zero-stuffed input, the 12 FiLM Linears concatenated), so gradients and
+optimizer state are in the same layouts and nothing is re-laid-out per step except the transposed / flipped copies a data gradient
+needs.  Every matrix product — forward convolutions, weight gradients (dY^T x im2col(X)^T), data gradients (a convolution of dY with
+the flipped weights) — is a vt_gemm call in exact-fp32 MFMA mode; GroupNorm+Mish+FiLM forward is the fused inference kernel, its
+backward / the losses / AdamW / EMA are csrc/vt_train.hip.  The orchestration below is host Python like the reference's training
+loop: a training step is a few thousand small launches (this is the f-4 row "built and parity-checked", not a tuned trainer).
+`state_dict()` / `load_state_dict()` speak the reference's key names and tensor layouts (checkpoint compatible).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+F32 = torch.float32
+
+
+def _sp(dev):
+    return L.stream_ptr(dev)
+
+
+def _empty(shape, dev):
+    return torch.empty(shape, dtype=F32, device=dev)
+
+
+# ---------------------------------------------------------------------------------------------- primitive wrappers
+def transpose(x2d: torch.Tensor) -> torch.Tensor:
+    M, N = x2d.shape
+    out = _empty((N, M), x2d.device)
+    L.check(L.lib().vt_transpose(L.ptr(x2d), L.ptr(out), M, N, _sp(x2d.device)), "vt_transpose")
+    return out
+
+
+def im2col_t(x: torch.Tensor, tout: int, taps: int, stride: int, off0: int) -> torch.Tensor:
+    B, tin, cin = x.shape
+    out = _empty((taps * cin, B * tout), x.device)
+    L.check(L.lib().vt_im2col_t(L.ptr(x), L.ptr(out), B, tin, tout, cin, taps, stride, off0, _sp(x.device)), "vt_im2col_t")
+    return out
+
+
+def zero_stuff(x: torch.Tensor) -> torch.Tensor:
+    B, T, Cc = x.shape
+    out = _empty((B, 2 * T, Cc), x.device)
+    L.check(L.lib().vt_zero_stuff(L.ptr(x), L.ptr(out), B, T, Cc, _sp(x.device)), "vt_zero_stuff")
+    return out
+
+
+def wflip(wp: torch.Tensor, cout: int, taps: int, cin: int) -> torch.Tensor:
+    out = _empty((cin, taps * cout), wp.device)
+    L.check(L.lib().vt_wflip(L.ptr(wp), L.ptr(out), cout, taps, cin, _sp(wp.device)), "vt_wflip")
+    return out
+
+
+def colsum(x2d: torch.Tensor) -> torch.Tensor:
+    M, N = x2d.shape
+    out = _empty((N,), x2d.device)
+    L.check(L.lib().vt_colsum(L.ptr(x2d), x2d.stride(0), L.ptr(out), M, N, 0, _sp(x2d.device)), "vt_colsum")
+    return out
+
+
+def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    assert a.shape == b.shape and a.is_contiguous() and b.is_contiguous()
+    L.check(L.lib().vt_add_(L.ptr(a), L.ptr(b), a.numel(), _sp(a.device)), "vt_add_")
+    return a
+
+
+def copy_cols(src: torch.Tensor, off: int, dst: torch.Tensor, doff: int, cols: int, accumulate: bool = False) -> None:
+    """dst[:, doff:doff+cols] (+)= src[:, off:off+cols] on 2-D views of row-contiguous buffers."""
+    rows = src.shape[0]
+    L.check(L.lib().vt_copy_cols(L.ptr(src), src.stride(0), off, L.ptr(dst), dst.stride(0), doff, rows, cols, int(accumulate), _sp(src.device)), "vt_copy_cols")
+
+
+def mish(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(x)
+    L.check(L.lib().vt_mish(L.ptr(x), L.ptr(dy), L.ptr(out), x.numel(), _sp(x.device)), "vt_mish")
+    return out
+
+
+def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    out = torch.empty_like(x)
+    L.check(L.lib().vt_gelu(L.ptr(x), L.ptr(dy), L.ptr(out), x.numel(), _sp(x.device)), "vt_gelu")
+    return out
+
+
+def conv_fwd(x, wp, b, k, stride, pad, tout):
+    return ops.conv1d_cl(x, wp, b, taps=k, cin=x.shape[2], tout=tout, stride=stride, off0=-pad)
+
+
+def conv_bwd(x, wp, dy, k, stride, pad):
+    """x [B,Tin,Cin], wp [Cout, k*Cin], dy [B,Tout,Cout] -> dx [B,Tin,Cin], dwp [Cout,k*Cin], db [Cout]."""
+    B, tin, cin = x.shape
+    tout, cout = dy.shape[1], dy.shape[2]
+    dy2 = dy.reshape(B * tout, cout)
+    dwp = ops.gemm(transpose(dy2), im2col_t(x, tout, k, stride, -pad))            # [Cout, M] x [k*Cin, M]^T
+    db = colsum(dy2)
+    wt = wflip(wp, cout, k, cin)                                                  # [Cin, k*Cout], taps reversed
+    src = dy if stride == 1 else zero_stuff(dy)                                   # strided conv: its data gradient is a transposed conv
+    dx = ops.conv1d_cl(src, wt, None, taps=k, cin=cout, tout=tin, stride=1, off0=pad - (k - 1))
+    return dx, dwp, db
+
+
+def convT_fwd(x, wc, b):
+    """ConvTranspose1d(k=4, s=2, p=1) as the stride-1 conv of the zero-stuffed input with wc[co][tp][ci] = W[ci][co][3 - tp]."""
+    xz = zero_stuff(x)
+    return ops.conv1d_cl(xz, wc, b, taps=4, cin=x.shape[2], tout=2 * x.shape[1], stride=1, off0=-2), xz
+
+
+def convT_bwd(xz, wc, dy, cin):
+    B, t2, cout = dy.shape
+    dy2 = dy.reshape(B * t2, cout)
+    dwc = ops.gemm(transpose(dy2), im2col_t(xz, t2, 4, 1, -2))
+    db = colsum(dy2)
+    wt = wflip(wc, cout, 4, cin)
+    dx = ops.conv1d_cl(dy, wt, None, taps=4, cin=cout, tout=t2 // 2, stride=2, off0=-1)    # d xz at the even (non-stuffed) positions
+    return dx, dwc, db
+
+
+def gn_fwd(c, gamma, beta, film=None, residual=None):
+    B, T, Cc = c.shape
+    out = ops.groupnorm_cl(c.reshape(1, B * T, Cc), None, gamma, beta, B=B, T=T, ngroups=8, film=film,
+                           residual=None if residual is None else residual.reshape(B * T, Cc))
+    return out.reshape(B, T, Cc)
+
+
+def gn_bwd(c, gamma, beta, film, dout):
+    B, T, Cc = c.shape
+    dev = c.device
+    dc, dgp, dbp = torch.empty_like(c), _empty((B, Cc), dev), _empty((B, Cc), dev)
+    dfilm = _empty((B, 2 * Cc), dev) if film is not None else None
+    L.check(L.lib().vt_gn_mish_bwd(L.ptr(c), L.ptr(gamma), L.ptr(beta), L.ptr(film), L.ptr(dout), L.ptr(dc), L.ptr(dgp), L.ptr(dbp), L.ptr(dfilm),
+                                   B, T, Cc, 8, 1e-5, _sp(dev)), "vt_gn_mish_bwd")
+    return dc, colsum(dgp), colsum(dbp), dfilm
+
+
+def linear_bwd(x, w, dy):
+    """y = x w^T + b: -> dx, dw, db."""
+    return ops.gemm(dy, transpose(w)), ops.gemm(transpose(dy), transpose(x)), colsum(dy)
+
+
+# ---------------------------------------------------------------------------------------------- the U-Net
+RB_ORDER = ["down_modules.0.0", "down_modules.0.1", "down_modules.1.0", "down_modules.1.1", "down_modules.2.0", "down_modules.2.1",
+            "mid_modules.0", "mid_modules.1", "up_modules.0.0", "up_modules.0.1", "up_modules.1.0", "up_modules.1.1"]
+RB_DIMS = [(10, 256), (256, 256), (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512), (1024, 512), (512, 512),
+           (1024, 256), (256, 256)]
+CIN0 = 16          # the 10 action channels padded to a multiple of 16 (GEMM k alignment); padded weight columns stay zero
+
+
+def _pack_conv(w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
+    cout, cin, k = w.shape
+    cp = cin_pad or cin
+    o = torch.zeros(cout, k, cp, dtype=F32)
+    o[:, :, :cin] = w.permute(0, 2, 1)
+    return o.reshape(cout, k * cp)
+
+
+def _unpack_conv(wp: torch.Tensor, cin: int, k: int) -> torch.Tensor:
+    cout = wp.shape[0]
+    return wp.reshape(cout, k, -1)[:, :, :cin].permute(0, 2, 1).contiguous()
+
+
+def _pack_convT(w: torch.Tensor) -> torch.Tensor:           # [Cin][Cout][4] -> wc [Cout][4*Cin], wc[co][tp][ci] = w[ci][co][3 - tp]
+    cin, cout, k = w.shape
+    return w.flip(2).permute(1, 2, 0).contiguous().reshape(cout, k * cin)
+
+
+def _unpack_convT(wc: torch.Tensor, cin: int) -> torch.Tensor:
+    cout = wc.shape[0]
+    return wc.reshape(cout, 4, cin).permute(2, 0, 1).flip(2).contiguous()
+
+
+class TrainUNet:
+    """One DiffusionConditionalUnet1D (input_dim 10, cond 256, dsed 256, down_dims [256, 512, 512], k 5, 8 groups) with packed fp32
+    parameters `self.p`, a forward that records what the backward needs, and the backward filling `self.g` (same keys as `self.p`)."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        self.device = torch.device(device)
+        self.p: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self.g: Dict[str, torch.Tensor] = {}
+        self.load_state_dict(sd)
+
+    # ---- reference layout <-> packed layout
+    def load_state_dict(self, sd):
+        g = lambda k: sd[k].detach().to("cpu", F32)
+        P = OrderedDict()
+        P["t1.w"], P["t1.b"] = g("diffusion_step_encoder.1.weight"), g("diffusion_step_encoder.1.bias")
+        P["t2.w"], P["t2.b"] = g("diffusion_step_encoder.3.weight"), g("diffusion_step_encoder.3.bias")
+        P["film.w"] = torch.cat([g(f"{rb}.cond_encoder.1.weight") for rb in RB_ORDER], dim=0)
+        P["film.b"] = torch.cat([g(f"{rb}.cond_encoder.1.bias") for rb in RB_ORDER], dim=0)
+        for i, rb in enumerate(RB_ORDER):
+            cin, cout = RB_DIMS[i]
+            cp = CIN0 if cin == 10 else cin
+            for j in (0, 1):
+                P[f"{rb}.c{j}.w"] = _pack_conv(g(f"{rb}.blocks.{j}.block.0.weight"), cp if j == 0 else None)
+                P[f"{rb}.c{j}.b"] = g(f"{rb}.blocks.{j}.block.0.bias")
+                P[f"{rb}.n{j}.w"], P[f"{rb}.n{j}.b"] = g(f"{rb}.blocks.{j}.block.1.weight"), g(f"{rb}.blocks.{j}.block.1.bias")
+            if cin != cout:
+                P[f"{rb}.r.w"], P[f"{rb}.r.b"] = _pack_conv(g(f"{rb}.residual_conv.weight"), cp), g(f"{rb}.residual_conv.bias")
+        for i in (0, 1):
+            P[f"down{i}.w"], P[f"down{i}.b"] = _pack_conv(g(f"down_modules.{i}.2.conv.weight")), g(f"down_modules.{i}.2.conv.bias")
+            P[f"up{i}.w"], P[f"up{i}.b"] = _pack_convT(g(f"up_modules.{i}.2.conv.weight")), g(f"up_modules.{i}.2.conv.bias")
+        P["fc.w"], P["fc.b"] = _pack_conv(g("final_conv.0.block.0.weight")), g("final_conv.0.block.0.bias")
+        P["fn.w"], P["fn.b"] = g("final_conv.0.block.1.weight"), g("final_conv.0.block.1.bias")
+        fo = torch.zeros(CIN0, 256, dtype=F32)                               # the 10 output channels padded to 16 rows (zero rows stay zero)
+        fo[:10] = _pack_conv(g("final_conv.1.weight"))
+        fob = torch.zeros(CIN0, dtype=F32)
+        fob[:10] = g("final_conv.1.bias")
+        P["fo.w"], P["fo.b"] = fo, fob
+        self.p = OrderedDict((k, v.contiguous().to(self.device)) for k, v in P.items())
+
+    def _unpack(self, T: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+        """Packed tensors (parameters or gradients) -> the reference's keys / layouts (CPU)."""
+        c = {k: v.detach().cpu() for k, v in T.items()}
+        out = OrderedDict()
+        out["diffusion_step_encoder.1.weight"], out["diffusion_step_encoder.1.bias"] = c["t1.w"], c["t1.b"]
+        out["diffusion_step_encoder.3.weight"], out["diffusion_step_encoder.3.bias"] = c["t2.w"], c["t2.b"]
+        off = 0
+        for i, rb in enumerate(RB_ORDER):
+            cin, cout = RB_DIMS[i]
+            for j in (0, 1):
+                out[f"{rb}.blocks.{j}.block.0.weight"] = _unpack_conv(c[f"{rb}.c{j}.w"], cin if j == 0 else cout, 5)
+                out[f"{rb}.blocks.{j}.block.0.bias"] = c[f"{rb}.c{j}.b"]
+                out[f"{rb}.blocks.{j}.block.1.weight"], out[f"{rb}.blocks.{j}.block.1.bias"] = c[f"{rb}.n{j}.w"], c[f"{rb}.n{j}.b"]
+            out[f"{rb}.cond_encoder.1.weight"] = c["film.w"][off:off + 2 * cout].clone()
+            out[f"{rb}.cond_encoder.1.bias"] = c["film.b"][off:off + 2 * cout].clone()
+            off += 2 * cout
+            if cin != cout:
+                out[f"{rb}.residual_conv.weight"], out[f"{rb}.residual_conv.bias"] = _unpack_conv(c[f"{rb}.r.w"], cin, 1), c[f"{rb}.r.b"]
+        for i, ch in ((0, 256), (1, 512)):
+            out[f"down_modules.{i}.2.conv.weight"], out[f"down_modules.{i}.2.conv.bias"] = _unpack_conv(c[f"down{i}.w"], ch, 3), c[f"down{i}.b"]
+        for i, ch in ((0, 512), (1, 256)):
+            out[f"up_modules.{i}.2.conv.weight"], out[f"up_modules.{i}.2.conv.bias"] = _unpack_convT(c[f"up{i}.w"], ch), c[f"up{i}.b"]
+        out["final_conv.0.block.0.weight"], out["final_conv.0.block.0.bias"] = _unpack_conv(c["fc.w"], 256, 5), c["fc.b"]
+        out["final_conv.0.block.1.weight"], out["final_conv.0.block.1.bias"] = c["fn.w"], c["fn.b"]
+        out["final_conv.1.weight"], out["final_conv.1.bias"] = _unpack_conv(c["fo.w"][:10].contiguous(), 256, 1), c["fo.b"][:10].clone()
+        return out
+
+    def state_dict(self):
+        return self._unpack(self.p)
+
+    def grads(self):
+        return self._unpack(self.g)
+
+    # ---- residual block
+    def _rb_fwd(self, rb, x, film):
+        p = self.p
+        T = x.shape[1]
+        c1 = conv_fwd(x, p[f"{rb}.c0.w"], p[f"{rb}.c0.b"], 5, 1, 2, T)
+        f = gn_fwd(c1, p[f"{rb}.n0.w"], p[f"{rb}.n0.b"], film=film)
+        c2 = conv_fwd(f, p[f"{rb}.c1.w"], p[f"{rb}.c1.b"], 5, 1, 2, T)
+        res = conv_fwd(x, p[f"{rb}.r.w"], p[f"{rb}.r.b"], 1, 1, 0, T) if f"{rb}.r.w" in p else x
+        out = gn_fwd(c2, p[f"{rb}.n1.w"], p[f"{rb}.n1.b"], residual=res)
+        return out, (x, c1, f, c2, film)
+
+    def _rb_bwd(self, rb, saved, dout):
+        p, g = self.p, self.g
+        x, c1, f, c2, film = saved
+        dc2, g[f"{rb}.n1.w"], g[f"{rb}.n1.b"], _ = gn_bwd(c2, p[f"{rb}.n1.w"], p[f"{rb}.n1.b"], None, dout)
+        df, g[f"{rb}.c1.w"], g[f"{rb}.c1.b"] = conv_bwd(f, p[f"{rb}.c1.w"], dc2, 5, 1, 2)
+        dc1, g[f"{rb}.n0.w"], g[f"{rb}.n0.b"], dfilm = gn_bwd(c1, p[f"{rb}.n0.w"], p[f"{rb}.n0.b"], film, df)
+        dx, g[f"{rb}.c0.w"], g[f"{rb}.c0.b"] = conv_bwd(x, p[f"{rb}.c0.w"], dc1, 5, 1, 2)
+        if f"{rb}.r.w" in p:
+            dxr, g[f"{rb}.r.w"], g[f"{rb}.r.b"] = conv_bwd(x, p[f"{rb}.r.w"], dout, 1, 1, 0)
+            add_(dx, dxr)
+        else:
+            add_(dx, dout.contiguous())
+        return dx, dfilm
+
+    # ---- forward / backward of the whole net
+    def forward(self, sample: torch.Tensor, t: torch.Tensor, cond: torch.Tensor) -> torch.Tensor:
+        """sample [B,T,10], t [B], cond [B,256] (fp32, device) -> [B,T,10]; records the tape for `backward`."""
+        p, dev = self.p, self.device
+        B, T, D = sample.shape
+        if T % 4 or (B * T // 4) % 16:
+            raise ValueError("TrainUNet: T must be a multiple of 4 and B*T/4 a multiple of 16")
+        pe = _empty((B, 256), dev)
+        L.check(L.lib().vt_posemb(L.ptr(t), L.ptr(pe), B, 256, _sp(dev)), "vt_posemb")
+        h1 = ops.gemm(pe, p["t1.w"], p["t1.b"])
+        h1m = mish(h1)
+        temb = ops.gemm(h1m, p["t2.w"], p["t2.b"])
+        gfeat = _empty((B, 512), dev)
+        copy_cols(temb, 0, gfeat, 0, 256)
+        copy_cols(cond, 0, gfeat, 256, 256)
+        gm = mish(gfeat)
+        film_all = ops.gemm(gm, p["film.w"], p["film.b"])                       # [B, 10752]
+        films, off = [], 0
+        for (cin, cout) in RB_DIMS:
+            fl = _empty((B, 2 * cout), dev)
+            copy_cols(film_all, off, fl, 0, 2 * cout)
+            films.append(fl)
+            off += 2 * cout
+        x = torch.zeros(B, T, CIN0, dtype=F32, device=dev)
+        copy_cols(sample.reshape(B * T, D), 0, x.reshape(B * T, CIN0), 0, D)
+        tape = {"pe": pe, "h1": h1, "h1m": h1m, "gfeat": gfeat, "gm": gm, "rb": [None] * 12, "B": B, "T": T, "D": D}
+        rb = RB_ORDER
+
+        def run(i, x):
+            out, tape["rb"][i] = self._rb_fwd(rb[i], x, films[i])
+            return out
+        x = run(1, run(0, x))
+        tape["d0_in"] = x
+        x = conv_fwd(x, p["down0.w"], p["down0.b"], 3, 2, 1, T // 2)
+        x = run(3, run(2, x))
+        h1s = x
+        tape["d1_in"] = x
+        x = conv_fwd(x, p["down1.w"], p["down1.b"], 3, 2, 1, T // 4)
+        x = run(5, run(4, x))
+        h2 = x
+        x = run(7, run(6, x))
+        xc = _empty((B, T // 4, 1024), dev)
+        copy_cols(x.reshape(-1, 512), 0, xc.reshape(-1, 1024), 0, 512)
+        copy_cols(h2.reshape(-1, 512), 0, xc.reshape(-1, 1024), 512, 512)
+        x = run(9, run(8, xc))
+        x, tape["u0_xz"] = convT_fwd(x, p["up0.w"], p["up0.b"])
+        xc = _empty((B, T // 2, 1024), dev)
+        copy_cols(x.reshape(-1, 512), 0, xc.reshape(-1, 1024), 0, 512)
+        copy_cols(h1s.reshape(-1, 512), 0, xc.reshape(-1, 1024), 512, 512)
+        x = run(11, run(10, xc))
+        x, tape["u1_xz"] = convT_fwd(x, p["up1.w"], p["up1.b"])
+        tape["fc_in"] = x
+        cf = conv_fwd(x, p["fc.w"], p["fc.b"], 5, 1, 2, T)
+        y = gn_fwd(cf, p["fn.w"], p["fn.b"])
+        tape["cf"], tape["y"] = cf, y
+        out16 = conv_fwd(y, p["fo.w"], p["fo.b"], 1, 1, 0, T)                  # [B, T, 16]: channels 10..15 are the zero padding
+        out = _empty((B, T, D), dev)
+        copy_cols(out16.reshape(B * T, CIN0), 0, out.reshape(B * T, D), 0, D)
+        self._tape = tape
+        return out
+
+    def backward(self, dout: torch.Tensor) -> torch.Tensor:
+        """dout [B,T,10] = d loss / d output -> fills self.g, returns d loss / d cond [B,256]."""
+        p, g, tp, dev = self.p, self.g, self._tape, self.device
+        B, T = tp["B"], tp["T"]
+        dfilm_all = _empty((B, p["film.w"].shape[0]), dev)
+        offs, o = [], 0
+        for (_, cout) in RB_DIMS:
+            offs.append(o)
+            o += 2 * cout
+
+        def back(i, d):
+            dx, dfl = self._rb_bwd(RB_ORDER[i], tp["rb"][i], d)
+            copy_cols(dfl, 0, dfilm_all, offs[i], dfl.shape[1])
+            return dx
+        d16 = torch.zeros(B, T, CIN0, dtype=F32, device=dev)
+        copy_cols(dout.contiguous().reshape(B * T, tp["D"]), 0, d16.reshape(B * T, CIN0), 0, tp["D"])
+        dy, g["fo.w"], g["fo.b"] = conv_bwd(tp["y"], p["fo.w"], d16, 1, 1, 0)
+        dcf, g["fn.w"], g["fn.b"], _ = gn_bwd(tp["cf"], p["fn.w"], p["fn.b"], None, dy)
+        d, g["fc.w"], g["fc.b"] = conv_bwd(tp["fc_in"], p["fc.w"], dcf, 5, 1, 2)
+        d, g["up1.w"], g["up1.b"] = convT_bwd(tp["u1_xz"], p["up1.w"], d, 256)
+        dxc = back(10, back(11, d))                                             # [B, T/2, 1024]
+        d = _empty((B, T // 2, 512), dev)
+        dh1 = _empty((B, T // 2, 512), dev)
+        copy_cols(dxc.reshape(-1, 1024), 0, d.reshape(-1, 512), 0, 512)
+        copy_cols(dxc.reshape(-1, 1024), 512, dh1.reshape(-1, 512), 0, 512)
+        d, g["up0.w"], g["up0.b"] = convT_bwd(tp["u0_xz"], p["up0.w"], d, 512)
+        dxc = back(8, back(9, d))                                               # [B, T/4, 1024]
+        d = _empty((B, T // 4, 512), dev)
+        dh2 = _empty((B, T // 4, 512), dev)
+        copy_cols(dxc.reshape(-1, 1024), 0, d.reshape(-1, 512), 0, 512)
+        copy_cols(dxc.reshape(-1, 1024), 512, dh2.reshape(-1, 512), 0, 512)
+        d = back(6, back(7, d))
+        add_(d, dh2)                                                            # h2 feeds the mid blocks AND the first up block
+        d = back(4, back(5, d))
+        d, g["down1.w"], g["down1.b"] = conv_bwd(tp["d1_in"], p["down1.w"], d, 3, 2, 1)
+        add_(d, dh1)
+        d = back(2, back(3, d))
+        d, g["down0.w"], g["down0.b"] = conv_bwd(tp["d0_in"], p["down0.w"], d, 3, 2, 1)
+        back(0, back(1, d))                                                     # (h0 is never used by the up path: no extra term)
+        # FiLM Linears (concatenated), the Mish in front of them, the timestep MLP
+        dgm, g["film.w"], g["film.b"] = linear_bwd(tp["gm"], p["film.w"], dfilm_all)
+        dg = mish(tp["gfeat"], dgm)
+        dtemb, dcond = _empty((B, 256), dev), _empty((B, 256), dev)
+        copy_cols(dg, 0, dtemb, 0, 256)
+        copy_cols(dg, 256, dcond, 0, 256)
+        dh1m, g["t2.w"], g["t2.b"] = linear_bwd(tp["h1m"], p["t2.w"], dtemb)
+        dh1 = mish(tp["h1"], dh1m)
+        _, g["t1.w"], g["t1.b"] = linear_bwd(tp["pe"], p["t1.w"], dh1)
+        self._tape = None
+        return dcond
+
+
+# ---------------------------------------------------------------------------------------------- the observation MLP
+class TrainMLP:
+    """Linear-GELU-Linear-GELU-Linear (bridge_controller.py:42-48), keys '0.weight', '0.bias', '2.*', '4.*'; K padded to 16."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device):
+        self.device = torch.device(device)
+        self.kin = sd["0.weight"].shape[1]
+        self.kpad = (self.kin + 15) // 16 * 16
+        w0 = torch.zeros(sd["0.weight"].shape[0], self.kpad, dtype=F32)
+        w0[:, :self.kin] = sd["0.weight"].detach().to("cpu", F32)
+        g = lambda k: sd[k].detach().to("cpu", F32).contiguous().to(self.device)
+        self.p = OrderedDict([("0.weight", w0.to(self.device)), ("0.bias", g("0.bias")), ("2.weight", g("2.weight")), ("2.bias", g("2.bias")),
+                              ("4.weight", g("4.weight")), ("4.bias", g("4.bias"))])
+        self.g: Dict[str, torch.Tensor] = {}
+
+    def _unpack(self, T):
+        out = OrderedDict((k, v.detach().cpu()) for k, v in T.items())
+        out["0.weight"] = out["0.weight"][:, :self.kin].contiguous()
+        return out
+
+    def state_dict(self):
+        return self._unpack(self.p)
+
+    def grads(self):
+        return self._unpack(self.g)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        B = x.shape[0]
+        xp = torch.zeros(B, self.kpad, dtype=F32, device=self.device)
+        copy_cols(x, 0, xp, 0, self.kin)
+        a1 = ops.gemm(xp, self.p["0.weight"], self.p["0.bias"])
+        h1 = gelu(a1)
+        a2 = ops.gemm(h1, self.p["2.weight"], self.p["2.bias"])
+        h2 = gelu(a2)
+        self._tape = (xp, a1, h1, a2, h2)
+        return ops.gemm(h2, self.p["4.weight"], self.p["4.bias"])
+
+    def backward(self, dout: torch.Tensor) -> None:
+        xp, a1, h1, a2, h2 = self._tape
+        dh2, self.g["4.weight"], self.g["4.bias"] = linear_bwd(h2, self.p["4.weight"], dout)
+        dh1, self.g["2.weight"], self.g["2.bias"] = linear_bwd(h1, self.p["2.weight"], gelu(a2, dh2))
+        _, self.g["0.weight"], self.g["0.bias"] = linear_bwd(xp, self.p["0.weight"], gelu(a1, dh1))
+        self._tape = None
+
+
+# ---------------------------------------------------------------------------------------------- the training step
+_GAMMA = {"2^0.5*t(t-1)": 0, "(2t(t-1))^0.5": 1, "(1-t)^2(2t)^0.5": 2}
+
+
+class SITrainer:
+    """get_loss + backward + AdamW + EMA for `StochasticInterpolants` (+ the observation MLP), one step per `train_step` call.
+
+    net_sd: the reference's `InterpolantsConditionalUnet1D` state dict (keys 'v_net.*', 's_net.*', 'b_net.*'); mlp_sd: state_encoder's.
+    Hyper-parameters as bridge_train.py:49-58 (AdamW) and bridge_model.py:433 (EMA decay 0.75, torch_ema warm-up)."""
+
+    def __init__(self, net_sd, mlp_sd=None, *, gamma_type="2^0.5*t(t-1)", interpolant_type="linear", beta_max=0.03, lr=1e-4, weight_decay=1e-6,
+                 betas=(0.9, 0.999), eps=1e-8, ema_decay=0.75, device="cuda"):
+        if interpolant_type != "linear":
+            raise NotImplementedError("only the 'linear' interpolant is trained on the device")
+        if gamma_type not in _GAMMA:
+            raise NotImplementedError(gamma_type)
+        self.device = L.require_gpu(device)
+        self.gamma_type, self.d, self.t_min = _GAMMA[gamma_type], beta_max, 0.001
+        self.nets = OrderedDict((n, TrainUNet({k[len(n) + 1:]: v for k, v in net_sd.items() if k.startswith(n + ".")}, self.device))
+                                for n in ("b_net", "v_net", "s_net"))
+        self.mlp = TrainMLP(mlp_sd, self.device) if mlp_sd is not None else None
+        self.lr, self.wd, self.betas, self.eps, self.ema_decay = lr, weight_decay, betas, eps, ema_decay
+        self.step_count = 0
+        self._m: Dict[str, torch.Tensor] = {}
+        self._v: Dict[str, torch.Tensor] = {}
+        self.shadow = {f"{n}.{k}": v.clone() for n, u in self.nets.items() for k, v in u.p.items()}     # EMA covers net.parameters()
+
+    def _all_params(self):
+        for n, u in self.nets.items():
+            for k in u.p:
+                yield f"{n}.{k}", u.p[k], u.g.get(k)
+        if self.mlp is not None:
+            for k in self.mlp.p:
+                yield f"state_encoder.{k}", self.mlp.p[k], self.mlp.g.get(k)
+
+    def get_loss(self, obs: torch.Tensor, vla_n: torch.Tensor, expert_n: torch.Tensor, t: torch.Tensor, z: torch.Tensor, *, backward: bool = True):
+        """obs: `obs_cond` [B,256], or the observation MLP's input [B, 2*Dv+13] when the trainer owns the MLP; vla_n / expert_n
+        [B,T,10] normalised source / target; t [B] in [0,1] (the reference's torch.rand draw); z [B,T,10] N(0,1) (scaled by beta_max
+        here, as `interpolant` does) -> (loss, {'v_loss','s_loss','b_loss'}) as python floats; gradients are left in the nets."""
+        dev = self.device
+        f = lambda a: a.to(dev, F32).contiguous()
+        obs, x0, x1, t, z = f(obs), f(vla_n), f(expert_n), f(t), f(z) * self.d
+        B, T, D = x0.shape
+        cond = self.mlp.forward(obs) if self.mlp is not None else obs
+        xt, tv, ts, tb = (torch.empty_like(x0) for _ in range(4))
+        tc = _empty((B,), dev)
+        L.check(L.lib().vt_si_qsample(L.ptr(x0), L.ptr(x1), L.ptr(z), L.ptr(t), L.ptr(xt), L.ptr(tv), L.ptr(ts), L.ptr(tb), L.ptr(tc), B, T * D,
+                                      self.gamma_type, self.t_min, _sp(dev)), "vt_si_qsample")
+        losses, dcond = {}, None
+        for name, tgt in (("v_net", tv), ("s_net", ts), ("b_net", tb)):
+            out = self.nets[name].forward(xt, tc, cond)
+            dout, loss = torch.empty_like(out), _empty((1,), dev)
+            L.check(L.lib().vt_si_loss(L.ptr(out), L.ptr(tgt), L.ptr(dout), L.ptr(loss), B, T * D, _sp(dev)), "vt_si_loss")
+            losses[name[0] + "_loss"] = loss
+            if backward:
+                dc = self.nets[name].backward(dout)
+                dcond = dc if dcond is None else add_(dcond, dc)
+        if backward and self.mlp is not None:
+            self.mlp.backward(dcond)
+        self.last_dcond = dcond
+        vals = {k: float(v.item()) for k, v in losses.items()}
+        return vals["v_loss"] + vals["s_loss"] + vals["b_loss"], vals
+
+    def optimizer_step(self):
+        """AdamW on every trained tensor, then the EMA update of the net parameters (bridge_train.py:331-334)."""
+        self.step_count += 1
+        lib, dev = L.lib(), self.device
+        for name, p, g in self._all_params():
+            if g is None:
+                raise RuntimeError(f"no gradient for {name}: call get_loss first")
+            if name not in self._m:
+                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+            L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
+                                 self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
+        decay = min(self.ema_decay, (1 + self.step_count) / (10 + self.step_count))          # torch_ema's warm-up
+        for name, sh in self.shadow.items():
+            n, k = name.split(".", 1)
+            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), decay, _sp(dev)), "vt_ema_update")
+
+    def train_step(self, obs, vla_n, expert_n, t, z):
+        loss, info = self.get_loss(obs, vla_n, expert_n, t, z)
+        self.optimizer_step()
+        return loss, info
+
+    def net_state_dict(self):
+        return OrderedDict((f"{n}.{k}", v) for n, u in self.nets.items() for k, v in u.state_dict().items())
+
+    def ema_state_dict(self):
+        out = OrderedDict()
+        for n, u in self.nets.items():
+            for k, v in u._unpack({k: self.shadow[f"{n}.{k}"] for k in u.p}).items():
+                out[f"{n}.{k}"] = v
+        return out
+
+    def net_grads(self):
+        return OrderedDict((f"{n}.{k}", v) for n, u in self.nets.items() for k, v in u.grads().items())
