@@ -96,9 +96,9 @@ __device__ __forceinline__ float mish_f(float x) { return act_apply(x, VT_ACT_MI
 // d/dx [x tanh(softplus(x))] = tanh(sp) + x (1 - tanh(sp)^2) sigmoid(x)
 __device__ __forceinline__ float mish_grad(float x) {
   if (x > 20.0f) return 1.0f;
-  const float e = fast_exp(x), w = e * (e + 2.0f);
-  const float th = w * __builtin_amdgcn_rcpf(w + 2.0f);
-  const float sg = e * __builtin_amdgcn_rcpf(1.0f + e);
+  const float e = expf(x), w = e * (e + 2.0f);           // libm exp and true divisions: gradients are not the place for the ~1 ulp shortcuts
+  const float th = w / (w + 2.0f);
+  const float sg = e / (1.0f + e);
   return th + x * (1.0f - th * th) * sg;
 }
 __global__ void mish_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
