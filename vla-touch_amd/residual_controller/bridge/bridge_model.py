@@ -145,6 +145,29 @@ class StochasticInterpolants:
             return x_target, x_target_traj
         return x_target
 
+    def get_loss(self, batch_dict, device, t=None, z=None, backward=True):
+        """The three interpolant losses on one batch (bridge_model.py:221-247): batch_dict['obs_cond' | 'vla_act' | 'expert_act'] ->
+        (loss, {'v_loss','s_loss','b_loss'}) as 0-d tensors.  The reference returns an autograd graph; here the backward pass runs
+        inside the call (`backward=True`) and leaves the gradients in `self.loss_trainer` (a `vlatouch.train.SITrainer` over the
+        current net parameters), whose `optimizer_step()` applies AdamW + EMA.  `t` [B] / `z` [B,T,D] replace the reference's
+        in-function `torch.rand` / `torch.randn_like` draws when given.  Training the observation MLP as well goes through
+        `residual_controller.bridge_train.DiffusionControllerTrainer`."""
+        from vlatouch.train import SITrainer
+        dev = torch.device(device)
+        key = (self.net.version, str(dev))
+        if getattr(self, "_loss_trainer_key", None) != key:
+            self.loss_trainer = SITrainer(self.net.state_dict(), None, gamma_type=self.gamma_type, interpolant_type=self.interpolant_type,
+                                          beta_max=self.d, ema_decay=self.ema.decay, device=dev)
+            self._loss_trainer_key = key
+        x0 = torch.as_tensor(batch_dict['vla_act'])
+        if t is None:
+            t = torch.rand(x0.shape[0], device=dev)
+        if z is None:
+            z = torch.randn(tuple(x0.shape), device=dev)
+        loss, info = self.loss_trainer.get_loss(batch_dict['obs_cond'], x0, batch_dict['expert_act'], t, z, backward=backward)
+        as_t = lambda v: torch.tensor(v, dtype=torch.float32, device=dev)
+        return as_t(loss), {k: as_t(v) for k, v in info.items()}
+
     def train(self):
         if self.net is not None:
             self.net.train()

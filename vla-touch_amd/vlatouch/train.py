@@ -532,5 +532,13 @@ class SITrainer:
                 out[f"{n}.{k}"] = v
         return out
 
+    def load_ema(self, ema_sd, num_updates: int) -> None:
+        """Adopt EMA shadow tensors given in the net's state-dict layout (a checkpoint's `ema.shadow_params` zipped with the net's keys)."""
+        for n in self.nets:
+            tmp = TrainUNet({k[len(n) + 1:]: v for k, v in ema_sd.items() if k.startswith(n + ".")}, self.device)
+            for k, v in tmp.p.items():
+                self.shadow[f"{n}.{k}"] = v
+        self.step_count = int(num_updates)
+
     def net_grads(self):
         return OrderedDict((f"{n}.{k}", v) for n, u in self.nets.items() for k, v in u.grads().items())
