@@ -245,6 +245,25 @@ int vt_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
 int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_t stream);
 int vt_posemb(const float* t, float* out, int B, int dim, vt_stream_t stream);                    /* SinusoidalPosEmb: [sin | cos] */
 
+/* ---- LSTM residual head training (lstm_step_controller.py:176-211 forward, :321-337 get_loss; lstm_train.py:26-33, 129-133).
+ * Batch-major sequences [B][T][C]; `t` is the tick a call works on.  Gate order i, f, g, o (torch.nn.LSTM).
+ * vt_lstm_cell_fwd: a = gx[b][t] (+ gh[b], required for t > 0) -> act[b][t][4H] (activated gates), cseq[b][t], hseq[b][t],
+ *                   hprev[b][t+1] (= h_t; hprev[b][0] = 0), hcur[b] (contiguous copy of h_t).
+ * vt_lstm_cell_bwd: dh = dhseq[b][t] (+ dh_rec[b], required for t < T-1); writes pre-activation gradients to dgates[b][t][4H] and
+ *                   dgcur[b][4H]; dc_next[b] carries dL/dc between ticks (ignored on input at t = T-1).
+ * vt_ln_bwd:        LayerNorm backward: dx, and dyxh = dy * x_hat whose column sums are d gamma (d beta = column sums of dy).
+ * vt_bcast_mid / vt_sum_mid: dst[b][t][doff + c] = src[b][c] and its gradient out[b][c] = sum_t src[b][t][off + c].
+ * vt_mse_residual:  pred = base + delta (base may be null), loss = mean((pred - target)^2), ddelta = 2 (pred - target) / n. */
+int vt_lstm_cell_fwd(const float* gx, const float* gh, float* act, float* cseq, float* hseq, float* hprev, float* hcur, int B, int T, int H,
+                     int t, vt_stream_t stream);
+int vt_lstm_cell_bwd(const float* dhseq, const float* dh_rec, const float* act, const float* cseq, float* dc_next, float* dgates, float* dgcur,
+                     int B, int T, int H, int t, vt_stream_t stream);
+int vt_ln_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dyxh, int rows, int C, float eps, vt_stream_t stream);
+int vt_bcast_mid(const float* src, float* dst, long ldd, int doff, int B, int T, int C, vt_stream_t stream);
+int vt_sum_mid(const float* src, long lds, int off, float* out, int B, int T, int C, vt_stream_t stream);
+int vt_mul_(float* a, const float* b, long n, vt_stream_t stream);
+int vt_mse_residual(const float* base, const float* delta, const float* target, float* pred, float* ddelta, float* loss, long n, vt_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -143,3 +143,77 @@ def test_trainer_mirror_steps_sync_and_checkpoint_round_trip(tmp_path):
     assert abs(l2 - l1) < 1e-5 * max(1.0, abs(l1)), (l1, l2)
     out = ctrl2.predict(batch["states"][:, 1], batch["vla_actions"], batch["images_cam1"][:, -1], batch["images_cam2"][:, -1], batch["forces"][:, 1])
     assert out.shape == (8, 16, 10) and bool(torch.isfinite(out).all())
+
+
+# ------------------------------------------------------------------------------------------------ LSTM residual head
+def test_lstm_training_step_matches_reference_autograd_adamw():
+    """g14: TactileLSTMController.get_loss + backward + AdamW + cosine LR of the REFERENCE (eval-mode dropout), two steps."""
+    from vlatouch.train import LstmTrainer
+    from tools.make_golden_train_lstm import lstm_train_inputs
+    g = np.load(f"{cases.GOLDEN}/g14_train_lstm.npz")
+    names = [str(n) for n in g["names"]]
+    tr = LstmTrainer(cases.lstm_mods(), lr=1e-4, weight_decay=1e-6, device="cuda:0")
+    for step in (1, 2):
+        inp = lstm_train_inputs(step)
+        tr.lr = 1e-4 if step == 1 else 9.999999997779339e-05
+        loss, pred = tr.get_loss(inp["obs_in"], inp["vla_n"], inp["forces"], inp["expert_n"], masks=None)
+        assert abs(loss - float(g[f"s{step}_loss"][0])) < 1e-5 * abs(float(g[f"s{step}_loss"][0])), (loss, g[f"s{step}_loss"])
+        assert float(np.abs(pred.cpu().numpy() - g[f"s{step}_pred"]).max()) < 2e-5
+        e = float(np.abs(tr.last_dcond.cpu().numpy() - g[f"s{step}_dcond"]).max())
+        assert e < 1e-4 * float(np.abs(g[f"s{step}_dcond"]).max()), e
+        flat = lambda d: {f"{m}.{k}": v for m, sd in d.items() for k, v in sd.items()}
+        grads = flat(tr.modules_grads())
+        assert set(names) == set(grads), set(names) ^ set(grads)
+        wg = check(g[f"s{step}_grad"], names, grads, "grad", 1e-4)
+        tr.optimizer_step()
+        wp = check(g[f"s{step}_param"], names, flat(tr.modules_state_dict()), "param", 1e-6)
+        print(f"[lstm train step {step}] loss {loss:.6f}; worst relative error: grads {wg:.2e}, params {wp:.2e}")
+
+
+def test_lstm_training_dropout_masks_against_torch_restatement():
+    """Training-mode arithmetic with injected keep-masks (inter-layer LSTM dropout, head dropout) against torch autograd on the CPU:
+    two single-layer nn.LSTMs with the mask between them are nn.LSTM(num_layers=2, dropout=p) for that mask."""
+    from vlatouch.train import LstmTrainer
+    from tools.make_golden_train_lstm import lstm_train_inputs
+    mods = cases.lstm_mods()
+    inp = lstm_train_inputs(3)
+    B, T, H, p = 16, 16, 256, 0.1
+    gen = torch.Generator().manual_seed(9)
+    masks = {"lstm": (torch.rand(B, T, H, generator=gen) >= p).float() / (1 - p), "head": (torch.rand(B, T, H, generator=gen) >= p).float() / (1 - p)}
+    with torch.enable_grad():
+        nn = torch.nn
+        mlp = lambda sd, n: nn.Sequential(*[m for i in range(n) for m in ([nn.Linear(sd[f"{2 * i}.weight"].shape[1], sd[f"{2 * i}.weight"].shape[0])] +
+                                                                           ([nn.GELU()] if i + 1 < n else []))])
+        obs_e, force_e = mlp(mods["obs_encoder"], 3), mlp(mods["force_encoder"], 2)
+        obs_e.load_state_dict(mods["obs_encoder"]), force_e.load_state_dict(mods["force_encoder"])
+        l0, l1 = nn.LSTM(138, H, batch_first=True), nn.LSTM(H, H, batch_first=True)
+        l0.load_state_dict({k[:-1] + "0": v for k, v in mods["lstm"].items() if k.endswith("l0")})
+        l1.load_state_dict({k[:-1] + "0": v for k, v in mods["lstm"].items() if k.endswith("l1")})
+        hd = mods["output_head"]
+        lin0, ln, lin4 = nn.Linear(2 * H, H), nn.LayerNorm(H), nn.Linear(H, 10)
+        lin0.load_state_dict({"weight": hd["0.weight"], "bias": hd["0.bias"]}), ln.load_state_dict({"weight": hd["1.weight"], "bias": hd["1.bias"]})
+        lin4.load_state_dict({"weight": hd["4.weight"], "bias": hd["4.bias"]})
+        cond = obs_e(inp["obs_in"])
+        x = torch.cat([force_e(inp["forces"].reshape(B * T, 3)).reshape(B, T, -1), inp["vla_n"]], -1)
+        h0, _ = l0(x)
+        h1, _ = l1(h0 * masks["lstm"])
+        a = torch.nn.functional.gelu(ln(lin0(torch.cat([h1, cond[:, None].expand(B, T, H)], -1)))) * masks["head"]
+        pred = inp["vla_n"] + lin4(a)
+        loss = torch.nn.functional.mse_loss(pred, inp["expert_n"])
+        loss.backward()
+    tr = LstmTrainer(mods, device="cuda:0")
+    got, gp = tr.get_loss(inp["obs_in"], inp["vla_n"], inp["forces"], inp["expert_n"], masks=masks)
+    assert abs(got - float(loss)) < 1e-5 * float(loss) and float((gp.cpu() - pred.detach()).abs().max()) < 2e-5
+    G = tr.modules_grads()
+    ref = {"lstm.weight_ih_l0": l0.weight_ih_l0.grad, "lstm.weight_hh_l0": l0.weight_hh_l0.grad, "lstm.bias_hh_l0": l0.bias_hh_l0.grad,
+           "lstm.weight_ih_l1": l1.weight_ih_l0.grad, "lstm.weight_hh_l1": l1.weight_hh_l0.grad, "output_head.0.weight": lin0.weight.grad,
+           "output_head.1.weight": ln.weight.grad, "output_head.1.bias": ln.bias.grad, "output_head.4.weight": lin4.weight.grad,
+           "force_encoder.0.weight": force_e[0].weight.grad, "obs_encoder.0.weight": obs_e[0].weight.grad, "obs_encoder.4.bias": obs_e[4].bias.grad}
+    for k, want in ref.items():
+        m, kk = k.split(".", 1)
+        e = float((G[m][kk] - want).norm() / want.norm())
+        assert e < 1e-4, (k, e)
+    # 'draw' masks: a step runs, the loss is finite, parameters move
+    before = tr.modules_state_dict()["lstm"]["weight_hh_l1"].clone()
+    l = tr.train_step(inp["obs_in"], inp["vla_n"], inp["forces"], inp["expert_n"], masks="draw")
+    assert np.isfinite(l) and not torch.equal(before, tr.modules_state_dict()["lstm"]["weight_hh_l1"])

@@ -163,6 +163,13 @@ SIGNATURES = {
     "vt_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
     "vt_ema_update": (_I, [_P, _P, _L, _F, _P]),
     "vt_posemb": (_I, [_P, _P, _I, _I, _P]),
+    "vt_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vt_lstm_cell_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "vt_ln_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "vt_bcast_mid": (_I, [_P, _P, _L, _I, _I, _I, _I, _P]),
+    "vt_sum_mid": (_I, [_P, _L, _I, _P, _I, _I, _I, _P]),
+    "vt_mul_": (_I, [_P, _P, _L, _P]),
+    "vt_mse_residual": (_I, [_P, _P, _P, _P, _P, _P, _L, _P]),
     "vt_marker_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "vt_marker_detect": (_I, [_P, _I, _I, _I, _I, _I, C.c_double, C.c_double, _I, _P, _P, _I, _P, _P, _P]),
     "vt_marker_displacement": (_I, [_P, _P, _I, _I, _P, _I, _P, _P, _P]),

@@ -395,22 +395,28 @@ class TrainUNet:
 
 # ---------------------------------------------------------------------------------------------- the observation MLP
 class TrainMLP:
-    """Linear-GELU-Linear-GELU-Linear (bridge_controller.py:42-48), keys '0.weight', '0.bias', '2.*', '4.*'; K padded to 16."""
+    """Linear (-GELU-Linear)* : the reference's nn.Sequential MLPs with keys '0.weight', '0.bias', '2.*'[, '4.*'] (state_encoder
+    bridge_controller.py:42-48; obs_encoder / force_encoder lstm_step_controller.py:44-60).  The first layer's K is padded to 16."""
 
     def __init__(self, sd: Dict[str, torch.Tensor], device):
         self.device = torch.device(device)
-        self.kin = sd["0.weight"].shape[1]
+        self.idx = sorted(int(k.split(".")[0]) for k in sd if k.endswith(".weight"))
+        first = f"{self.idx[0]}.weight"
+        self.kin = sd[first].shape[1]
         self.kpad = (self.kin + 15) // 16 * 16
-        w0 = torch.zeros(sd["0.weight"].shape[0], self.kpad, dtype=F32)
-        w0[:, :self.kin] = sd["0.weight"].detach().to("cpu", F32)
+        w0 = torch.zeros(sd[first].shape[0], self.kpad, dtype=F32)
+        w0[:, :self.kin] = sd[first].detach().to("cpu", F32)
         g = lambda k: sd[k].detach().to("cpu", F32).contiguous().to(self.device)
-        self.p = OrderedDict([("0.weight", w0.to(self.device)), ("0.bias", g("0.bias")), ("2.weight", g("2.weight")), ("2.bias", g("2.bias")),
-                              ("4.weight", g("4.weight")), ("4.bias", g("4.bias"))])
+        self.p = OrderedDict()
+        for i in self.idx:
+            self.p[f"{i}.weight"] = w0.to(self.device) if i == self.idx[0] else g(f"{i}.weight")
+            self.p[f"{i}.bias"] = g(f"{i}.bias")
         self.g: Dict[str, torch.Tensor] = {}
+        self.first = first
 
     def _unpack(self, T):
         out = OrderedDict((k, v.detach().cpu()) for k, v in T.items())
-        out["0.weight"] = out["0.weight"][:, :self.kin].contiguous()
+        out[self.first] = out[self.first][:, :self.kin].contiguous()
         return out
 
     def state_dict(self):
@@ -421,21 +427,27 @@ class TrainMLP:
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         B = x.shape[0]
-        xp = torch.zeros(B, self.kpad, dtype=F32, device=self.device)
-        copy_cols(x, 0, xp, 0, self.kin)
-        a1 = ops.gemm(xp, self.p["0.weight"], self.p["0.bias"])
-        h1 = gelu(a1)
-        a2 = ops.gemm(h1, self.p["2.weight"], self.p["2.bias"])
-        h2 = gelu(a2)
-        self._tape = (xp, a1, h1, a2, h2)
-        return ops.gemm(h2, self.p["4.weight"], self.p["4.bias"])
+        h = torch.zeros(B, self.kpad, dtype=F32, device=self.device)
+        copy_cols(x, 0, h, 0, self.kin)
+        tape = []
+        for n, i in enumerate(self.idx):
+            a = ops.gemm(h, self.p[f"{i}.weight"], self.p[f"{i}.bias"])
+            tape.append((h, a))
+            h = gelu(a) if n + 1 < len(self.idx) else a
+        self._tape = tape
+        return h
 
-    def backward(self, dout: torch.Tensor) -> None:
-        xp, a1, h1, a2, h2 = self._tape
-        dh2, self.g["4.weight"], self.g["4.bias"] = linear_bwd(h2, self.p["4.weight"], dout)
-        dh1, self.g["2.weight"], self.g["2.bias"] = linear_bwd(h1, self.p["2.weight"], gelu(a2, dh2))
-        _, self.g["0.weight"], self.g["0.bias"] = linear_bwd(xp, self.p["0.weight"], gelu(a1, dh1))
+    def backward(self, dout: torch.Tensor) -> torch.Tensor:
+        """-> the gradient with respect to the (unpadded) input."""
+        d = dout
+        for n in range(len(self.idx) - 1, -1, -1):
+            i = self.idx[n]
+            h, a = self._tape[n]
+            if n + 1 < len(self.idx):
+                d = gelu(a, d)
+            d, self.g[f"{i}.weight"], self.g[f"{i}.bias"] = linear_bwd(h, self.p[f"{i}.weight"], d)
         self._tape = None
+        return d
 
 
 # ---------------------------------------------------------------------------------------------- the training step
@@ -542,3 +554,214 @@ class SITrainer:
 
     def net_grads(self):
         return OrderedDict((f"{n}.{k}", v) for n, u in self.nets.items() for k, v in u.grads().items())
+
+
+# ---------------------------------------------------------------------------------------------- the LSTM residual head
+def _cosine_lr(base: float, step: int, t_max: int = 100000) -> float:
+    """optim.lr_scheduler.CosineAnnealingLR(T_max=100000, eta_min=lr/10) (bridge_train.py:59-61, lstm_train.py:31-33), closed form."""
+    import math
+    eta = base / 10
+    return eta + (base - eta) * (1 + math.cos(math.pi * step / t_max)) / 2
+
+
+class LstmTrainer:
+    """forward + get_loss + BPTT + AdamW for `TactileLSTMController` (lstm_step_controller.py:176-211, 321-337; lstm_train.py:26-33,
+    129-133).  `mods` = the checkpoint's 'modules' dict: obs_encoder / force_encoder (nn.Sequential MLPs), lstm (torch.nn.LSTM keys
+    weight_ih_l{k}, weight_hh_l{k}, bias_ih_l{k}, bias_hh_l{k}), output_head (0 Linear, 1 LayerNorm, 4 Linear).
+
+    Dropout (nn.LSTM inter-layer p=0.1, head p=`dropout`) is applied through explicit masks: `masks=None` is eval-mode arithmetic (what
+    the parity goldens pin, the reference in `.eval()` under autograd); `masks="draw"` draws Bernoulli keep-masks on the device each step as
+    training mode does; a dict {'lstm': [B,T,H] , 'head': [B,T,H]} of 0 / 1/(1-p) tensors injects them (tests)."""
+
+    def __init__(self, mods, *, lr=1e-4, weight_decay=1e-6, betas=(0.9, 0.999), eps=1e-8, lstm_dropout=0.1, head_dropout=0.1, device="cuda"):
+        self.device = dev = L.require_gpu(device)
+        g = lambda t: t.detach().to("cpu", F32).contiguous().to(dev)
+        self.obs = TrainMLP(mods["obs_encoder"], dev) if mods.get("obs_encoder") is not None else None
+        self.force = TrainMLP(mods["force_encoder"], dev)
+        ls = mods["lstm"]
+        self.nl = len([k for k in ls if k.startswith("weight_ih_l")])
+        self.H = ls["weight_hh_l0"].shape[1]
+        self.lstm: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+        self.kin, self.kpad = [], []
+        for l in range(self.nl):
+            w = ls[f"weight_ih_l{l}"].detach().to("cpu", F32)
+            kin = w.shape[1]
+            kp = (kin + 15) // 16 * 16
+            wp = torch.zeros(4 * self.H, kp, dtype=F32)
+            wp[:, :kin] = w
+            self.kin.append(kin), self.kpad.append(kp)
+            self.lstm[f"weight_ih_l{l}"] = wp.to(dev)
+            for k in (f"weight_hh_l{l}", f"bias_ih_l{l}", f"bias_hh_l{l}"):
+                self.lstm[k] = g(ls[k])
+        hd = mods["output_head"]
+        self.head = OrderedDict((k, g(hd[k])) for k in ("0.weight", "0.bias", "1.weight", "1.bias", "4.weight", "4.bias"))
+        self.gl: Dict[str, torch.Tensor] = {}
+        self.gh: Dict[str, torch.Tensor] = {}
+        self.lr, self.base_lr, self.wd, self.betas, self.eps = lr, lr, weight_decay, betas, eps
+        self.p_lstm, self.p_head = lstm_dropout, head_dropout
+        self.step_count = 0
+        self._m: Dict[str, torch.Tensor] = {}
+        self._v: Dict[str, torch.Tensor] = {}
+
+    # ---- one layer over the whole sequence
+    def _layer_fwd(self, l, X, B, T):
+        H, dev, lib, sp = self.H, self.device, L.lib(), _sp(self.device)
+        bias = self.lstm[f"bias_ih_l{l}"].clone()                               # b_ih + b_hh folded into the all-tick input projection
+        add_(bias, self.lstm[f"bias_hh_l{l}"])
+        gx = ops.gemm(X, self.lstm[f"weight_ih_l{l}"], bias)                  # [B*T, 4H], every tick at once
+        act, cseq = _empty((B * T, 4 * H), dev), _empty((B * T, H), dev)
+        hseq, hprev, hcur = _empty((B * T, H), dev), _empty((B * T, H), dev), _empty((B, H), dev)
+        gh = None
+        for t in range(T):
+            if t > 0:
+                gh = ops.gemm(hcur, self.lstm[f"weight_hh_l{l}"])
+            L.check(lib.vt_lstm_cell_fwd(L.ptr(gx), L.ptr(gh), L.ptr(act), L.ptr(cseq), L.ptr(hseq), L.ptr(hprev), L.ptr(hcur), B, T, H, t, sp),
+                    "vt_lstm_cell_fwd")
+        return hseq, (X, act, cseq, hprev)
+
+    def _layer_bwd(self, l, saved, dhseq, B, T):
+        X, act, cseq, hprev = saved
+        H, dev, lib, sp = self.H, self.device, L.lib(), _sp(self.device)
+        whh_t = transpose(self.lstm[f"weight_hh_l{l}"])                         # [H, 4H]: dh_{t-1} = dgates_t W_hh
+        dgates, dgcur, dc = _empty((B * T, 4 * H), dev), _empty((B, 4 * H), dev), _empty((B, H), dev)
+        dh_rec = None
+        for t in range(T - 1, -1, -1):
+            L.check(lib.vt_lstm_cell_bwd(L.ptr(dhseq), L.ptr(dh_rec), L.ptr(act), L.ptr(cseq), L.ptr(dc), L.ptr(dgates), L.ptr(dgcur), B, T, H, t, sp),
+                    "vt_lstm_cell_bwd")
+            if t > 0:
+                dh_rec = ops.gemm(dgcur, whh_t)
+        dX, self.gl[f"weight_ih_l{l}"], db = linear_bwd(X, self.lstm[f"weight_ih_l{l}"], dgates)
+        self.gl[f"weight_hh_l{l}"] = ops.gemm(transpose(dgates), transpose(hprev))
+        self.gl[f"bias_ih_l{l}"], self.gl[f"bias_hh_l{l}"] = db, db
+        return dX
+
+    def _mask(self, masks, key, shape, p):
+        if masks is None or p <= 0:
+            return None
+        if isinstance(masks, str):
+            if masks != "draw":
+                raise ValueError("masks must be None, 'draw' or a dict of tensors")
+            return (torch.rand(shape, device=self.device) >= p).to(F32) / (1.0 - p)
+        m = masks.get(key)
+        return None if m is None else m.to(self.device, F32).contiguous().reshape(shape)
+
+    def get_loss(self, obs, vla_n, forces, expert_n, *, masks=None, backward: bool = True):
+        """obs: obs_cond [B,H], or the obs_encoder's input [B, 2*Dv+state] when the trainer owns that MLP; vla_n / expert_n [B,T,D]
+        normalised; forces [B,T,F] -> (loss, pred [B,T,D]); gradients are left in the trainer."""
+        dev, lib, sp, H = self.device, L.lib(), _sp(self.device), self.H
+        f = lambda a: torch.as_tensor(a).to(dev, F32).contiguous()
+        obs, vla, forces, expert = f(obs), f(vla_n), f(forces), f(expert_n)
+        B, T, D = vla.shape
+        M = B * T
+        cond = self.obs.forward(obs) if self.obs is not None else obs
+        ef = self.force.forward(forces.reshape(M, -1))                           # [M, H/2]
+        X = torch.zeros(M, self.kpad[0], dtype=F32, device=dev)                  # [encoded force | vla action | 0]
+        copy_cols(ef, 0, X, 0, ef.shape[1])
+        copy_cols(vla.reshape(M, D), 0, X, ef.shape[1], D)
+        saved, lmasks = [], []
+        for l in range(self.nl):
+            hseq, sv = self._layer_fwd(l, X, B, T)
+            saved.append(sv)
+            if l + 1 < self.nl:
+                m = self._mask(masks, "lstm" if self.nl == 2 else f"lstm{l}", (M, H), self.p_lstm)
+                lmasks.append(m)
+                X = hseq
+                if m is not None:
+                    X = hseq.clone()
+                    L.check(lib.vt_mul_(L.ptr(X), L.ptr(m), X.numel(), sp), "vt_mul_")
+        comb = _empty((M, 2 * H), dev)
+        copy_cols(hseq, 0, comb, 0, H)
+        L.check(lib.vt_bcast_mid(L.ptr(cond), L.ptr(comb), 2 * H, H, B, T, H, sp), "vt_bcast_mid")
+        a1 = ops.gemm(comb, self.head["0.weight"], self.head["0.bias"])
+        n1 = ops.rownorm(a1, self.head["1.weight"], self.head["1.bias"], 1e-5)
+        g1_ = gelu(n1)
+        hm = self._mask(masks, "head", (M, H), self.p_head)
+        if hm is not None:
+            L.check(lib.vt_mul_(L.ptr(g1_), L.ptr(hm), g1_.numel(), sp), "vt_mul_")
+        delta = ops.gemm(g1_, self.head["4.weight"], self.head["4.bias"])
+        pred, ddelta, loss = _empty((M, D), dev), _empty((M, D), dev), _empty((1,), dev)
+        L.check(lib.vt_mse_residual(L.ptr(vla), L.ptr(delta), L.ptr(expert), L.ptr(pred), L.ptr(ddelta), L.ptr(loss), M * D, sp), "vt_mse_residual")
+        if backward:
+            Dp = (D + 15) // 16 * 16                                              # GEMM k alignment: the D = 10 outputs padded with zeros
+            ddp, w4p = torch.zeros(M, Dp, dtype=F32, device=dev), torch.zeros(Dp, H, dtype=F32, device=dev)
+            copy_cols(ddelta, 0, ddp, 0, D)
+            copy_cols(self.head["4.weight"], 0, w4p, 0, H)
+            dg1 = ops.gemm(ddp, transpose(w4p))
+            self.gh["4.weight"], self.gh["4.bias"] = ops.gemm(transpose(ddelta), transpose(g1_)), colsum(ddelta)
+            if hm is not None:
+                L.check(lib.vt_mul_(L.ptr(dg1), L.ptr(hm), dg1.numel(), sp), "vt_mul_")
+            dn1 = gelu(n1, dg1)
+            da1, dyxh = torch.empty_like(a1), torch.empty_like(a1)
+            L.check(lib.vt_ln_bwd(L.ptr(a1), L.ptr(self.head["1.weight"]), L.ptr(dn1), L.ptr(da1), L.ptr(dyxh), M, H, 1e-5, sp), "vt_ln_bwd")
+            self.gh["1.weight"], self.gh["1.bias"] = colsum(dyxh), colsum(dn1)
+            dcomb, self.gh["0.weight"], self.gh["0.bias"] = linear_bwd(comb, self.head["0.weight"], da1)
+            dcond = _empty((B, H), dev)
+            L.check(lib.vt_sum_mid(L.ptr(dcomb), 2 * H, H, L.ptr(dcond), B, T, H, sp), "vt_sum_mid")
+            dh = _empty((M, H), dev)
+            copy_cols(dcomb, 0, dh, 0, H)
+            for l in range(self.nl - 1, -1, -1):
+                dX = self._layer_bwd(l, saved[l], dh, B, T)
+                if l > 0:
+                    dh = dX                                                       # kpad == H for the upper layers
+                    if lmasks[l - 1] is not None:
+                        L.check(lib.vt_mul_(L.ptr(dh), L.ptr(lmasks[l - 1]), dh.numel(), sp), "vt_mul_")
+            def_ = _empty((M, ef.shape[1]), dev)
+            copy_cols(dX, 0, def_, 0, ef.shape[1])
+            self.force.backward(def_)
+            if self.obs is not None:
+                self.obs.backward(dcond)
+            self.last_dcond = dcond
+        return float(loss.item()), pred.reshape(B, T, D)
+
+    # ---- parameters in the reference's layout
+    def _all(self):
+        if self.obs is not None:
+            for k in self.obs.p:
+                yield f"obs_encoder.{k}", self.obs.p[k], self.obs.g.get(k)
+        for k in self.force.p:
+            yield f"force_encoder.{k}", self.force.p[k], self.force.g.get(k)
+        for k in self.lstm:
+            yield f"lstm.{k}", self.lstm[k], self.gl.get(k)
+        for k in self.head:
+            yield f"output_head.{k}", self.head[k], self.gh.get(k)
+
+    def _unpack_lstm(self, T):
+        out = OrderedDict()
+        for k, v in T.items():
+            v = v.detach().cpu()
+            if k.startswith("weight_ih_l"):
+                v = v[:, :self.kin[int(k[len("weight_ih_l"):])]].contiguous()
+            out[k] = v
+        return out
+
+    def modules_state_dict(self):
+        """{'obs_encoder', 'force_encoder', 'lstm', 'output_head'} as tactile_controller.pt stores them (lstm_step_controller.py:351-363)."""
+        out = {"force_encoder": self.force.state_dict(), "lstm": self._unpack_lstm(self.lstm),
+               "output_head": OrderedDict((k, v.detach().cpu()) for k, v in self.head.items())}
+        if self.obs is not None:
+            out["obs_encoder"] = self.obs.state_dict()
+        return out
+
+    def modules_grads(self):
+        out = {"force_encoder": self.force.grads(), "lstm": self._unpack_lstm(self.gl), "output_head": OrderedDict((k, v.detach().cpu()) for k, v in self.gh.items())}
+        if self.obs is not None:
+            out["obs_encoder"] = self.obs.grads()
+        return out
+
+    def optimizer_step(self):
+        self.step_count += 1
+        lib, dev = L.lib(), self.device
+        for name, p, g in self._all():
+            if g is None:
+                raise RuntimeError(f"no gradient for {name}: call get_loss first")
+            if name not in self._m:
+                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+            L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
+                                 self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
+
+    def train_step(self, obs, vla_n, forces, expert_n, *, masks="draw", schedule: bool = True):
+        if schedule:
+            self.lr = _cosine_lr(self.base_lr, self.step_count)
+        loss, _ = self.get_loss(obs, vla_n, forces, expert_n, masks=masks)
+        self.optimizer_step()
+        return loss
