@@ -217,3 +217,36 @@ def test_lstm_training_dropout_masks_against_torch_restatement():
     before = tr.modules_state_dict()["lstm"]["weight_hh_l1"].clone()
     l = tr.train_step(inp["obs_in"], inp["vla_n"], inp["forces"], inp["expert_n"], masks="draw")
     assert np.isfinite(l) and not torch.equal(before, tr.modules_state_dict()["lstm"]["weight_hh_l1"])
+
+
+def test_lstm_trainer_mirror_overfits_a_batch_and_round_trips(tmp_path):
+    """LSTMControllerTrainer (lstm_train.py:19): fixed batch -> the loss falls; trained tensors reach the controller, whose
+    inference kernels (predict_sequence / forward) then reproduce the trainer's own prediction; save -> load keeps them."""
+    from vlatouch import synth
+    from residual_controller.lstm_step_controller import TactileLSTMController
+    from residual_controller.lstm_train import LSTMControllerTrainer
+    dev = "cuda:0"
+    c = synth.DINOV2_CONFIGS["small"]
+    mk = lambda: TactileLSTMController(device=dev, precision="fp32",
+                                       image_state_dict=synth.torch_state_dict(synth.dinov2_shapes(c["hidden"], c["layers"]), prefix="dinov2-small."))
+    ctrl = mk()
+    stats = {k: v.cpu().numpy() for k, v in synth.unit_stats().items()}
+    tr = LSTMControllerTrainer(ctrl, _DataModule(stats), learning_rate=1e-3, checkpoint_dir=str(tmp_path / "ck"), device=dev)
+    batch = _batch(6)
+    batch["forces"] = batch["forces"][:, :18]                  # context 2 + horizon 16: forces[:, 1:-1] is the 16-tick window
+    l0 = tr.eval_step(batch)
+    losses = [tr.train_step(batch, masks=None) for _ in range(10)]
+    l1 = tr.eval_step(batch)
+    assert np.isfinite(losses).all() and l1 < 0.9 * l0, (l0, losses, l1)
+    tr._save_checkpoint("epoch_1")
+    bd = tr._prepare_batch(batch)
+    _, pred = tr.trainer.get_loss(bd["obs_in"], bd["vla_act"], bd["forces"], bd["expert_act"], masks=None, backward=False)
+    obs_cond = ctrl.encode_observation(batch["states"][:, 1], batch["images_cam1"][:, -1], batch["images_cam2"][:, -1])
+    fwd = ctrl.forward({"vla_act": bd["vla_act"], "obs_cond": obs_cond, "forces": bd["forces"]})
+    assert float((fwd - pred).abs().max()) < 2e-4, float((fwd - pred).abs().max())
+    lm = float(ctrl.get_loss({"vla_act": bd["vla_act"], "obs_cond": obs_cond, "forces": bd["forces"], "expert_act": bd["expert_act"]}))
+    assert abs(lm - l1) < 1e-4 * max(1.0, l1)
+    ctrl2 = mk()
+    tr2 = LSTMControllerTrainer(ctrl2, _DataModule(stats), learning_rate=1e-3, checkpoint_dir=str(tmp_path / "ck2"), device=dev)
+    tr2.load_checkpoint(str(tmp_path / "ck" / "epoch_1"))
+    assert abs(tr2.eval_step(batch) - l1) < 1e-6 * max(1.0, l1)

@@ -139,6 +139,14 @@ class TactileLSTMController:
                 out_n = out_n - vla_actions_n.to(out_n.device)
             return denormalize_actions(out_n, self.stats, 'expert')
 
+    def get_loss(self, batch_dict):
+        """F.mse_loss(forward(batch), expert_act) (lstm_step_controller.py:321-337) as a 0-d tensor.  Evaluation arithmetic (no
+        dropout) through the sequence kernel; the differentiated loss with AdamW lives in `vlatouch.train.LstmTrainer` /
+        `residual_controller.lstm_train.LSTMControllerTrainer`, which owns the optimiser state."""
+        pred = self.forward(batch_dict)
+        target = torch.as_tensor(batch_dict['expert_act']).to(pred.device, torch.float32)
+        return ((pred - target) ** 2).mean()
+
     def train(self, mode=True):
         for m in self.trainable_modules:
             m.train(mode)
