@@ -243,6 +243,12 @@ int vt_si_loss(const float* out, const float* target, float* dout, float* loss, 
 int vt_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
              int step, vt_stream_t stream);
 int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_t stream);
+/* the same two updates with the step-dependent scalars in DEVICE memory, hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t), 1 - ema_decay_t]:
+ * a captured graph of the training step stays valid while t advances (the host rewrites 16 bytes before each replay) */
+int vt_train_hyper(float lr, float beta1, float beta2, int step, float ema_decay, float* out4_host);   /* host-side: fills hyper for step t */
+int vt_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
+                 float weight_decay, vt_stream_t stream);
+int vt_ema_update_dev(float* shadow, const float* p, long n, const float* hyper, vt_stream_t stream);
 int vt_posemb(const float* t, float* out, int B, int dim, vt_stream_t stream);                    /* SinusoidalPosEmb: [sin | cos] */
 
 /* ---- LSTM residual head training (lstm_step_controller.py:176-211 forward, :321-337 get_loss; lstm_train.py:26-33, 129-133).

@@ -250,3 +250,23 @@ def test_lstm_trainer_mirror_overfits_a_batch_and_round_trips(tmp_path):
     tr2 = LSTMControllerTrainer(ctrl2, _DataModule(stats), learning_rate=1e-3, checkpoint_dir=str(tmp_path / "ck2"), device=dev)
     tr2.load_checkpoint(str(tmp_path / "ck" / "epoch_1"))
     assert abs(tr2.eval_step(batch) - l1) < 1e-6 * max(1.0, l1)
+
+
+def test_captured_training_step_equals_eager():
+    """SITrainer.capture / replay (one hipGraph per step, step-dependent scalars in device memory) == the eager step, bit for bit."""
+    from vlatouch.train import SITrainer
+    mk = lambda: SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), lr=1e-3, device="cuda:0")
+    a, b = mk(), mk()
+    b.capture(16)
+    for step in (1, 2, 3):
+        inp = train_inputs(step)
+        args = [inp[k].to("cuda:0") for k in ("obs_in", "vla_n", "expert_n", "t", "z")]
+        la, info = a.train_step(*args)
+        lb = b.replay(*args)
+        torch.cuda.synchronize()
+        assert all(float(lb[k]) == info[k] for k in info), (step, info, {k: float(v) for k, v in lb.items()})
+    pa, pb = a.net_state_dict(), b.net_state_dict()
+    assert all(torch.equal(pa[k], pb[k]) for k in pa)
+    ea, eb = a.ema_state_dict(), b.ema_state_dict()
+    assert all(torch.equal(ea[k], eb[k]) for k in ea)
+    assert all(torch.equal(x, y) for x, y in zip(a.mlp.state_dict().values(), b.mlp.state_dict().values()))

@@ -68,13 +68,25 @@ __global__ void wflip_kernel(const float* __restrict__ W, float* __restrict__ WT
   WT[i] = W[((long)co * taps + (taps - 1 - tp)) * Cin + ci];
 }
 
-// column sums of [M][N] (row pitch ld) -> out[N] (bias gradients; the [B][C] partials of the GroupNorm gains)
-__global__ void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, int M, int N, int accumulate) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int m = 0; m < M; ++m) s += x[(long)m * ld + n];        // fixed order: deterministic
-  out[n] = accumulate ? out[n] + s : s;
+// column sums of [M][N] (row pitch ld) -> out[N] (bias gradients; the [B][C] partials of the GroupNorm gains).  A block owns 32 columns
+// (128-B row segments) with 32 row lanes; each lane adds its rows in order, the lanes are combined by a fixed LDS tree: deterministic.
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out, int M, int N, int accumulate) {
+  __shared__ float part[32][33];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int m = r;
+    for (; m + 32 < M; m += 64) { s0 += x[(long)m * ld + n]; s1 += x[(long)(m + 32) * ld + n]; }
+    if (m < M) s0 += x[(long)m * ld + n];
+  }
+  part[r][c] = s0 + s1;
+  __syncthreads();
+  for (int h = 16; h > 0; h >>= 1) {
+    if (r < h) part[r][c] += part[r + h][c];
+    __syncthreads();
+  }
+  if (r == 0 && n < N) out[n] = accumulate ? out[n] + part[0][c] : part[0][c];
 }
 
 __global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
@@ -239,6 +251,25 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
   const float denom = sqrtf(vv) / bc2_sqrt + eps;
   p[i] = pv - (lr / bc1) * (mv / denom);
 }
+// the same update with the step-dependent scalars read from device memory (hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t), 1 - ema_decay_t]),
+// so that a captured hipGraph of the step can be replayed while the step count advances
+__global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                 const float* __restrict__ hyper, float b1, float b2, float eps, float wd) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
+  float pv = p[i] * (1.0f - lr * wd);
+  const float gv = g[i];
+  const float mv = b1 * m[i] + (1.0f - b1) * gv;
+  const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+  m[i] = mv; v[i] = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  p[i] = pv - (lr / bc1) * (mv / denom);
+}
+__global__ void ema_dev_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, const float* __restrict__ hyper) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) shadow[i] -= hyper[3] * (shadow[i] - p[i]);
+}
 // torch_ema: shadow -= (1 - decay) * (shadow - p)
 __global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, float one_minus_decay) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
@@ -282,7 +313,7 @@ int vt_wflip(const float* W, float* WT, int Cout, int taps, int Cin, vt_stream_t
 }
 int vt_colsum(const float* x, long ld, float* out, int M, int N, int accumulate, vt_stream_t s) {
   if (!x || !out || M < 1 || N < 1) return vt_fail(VT_ERR_ARG, "vt_colsum: bad argument");
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, x, ld, out, M, N, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(1024), 0, (hipStream_t)s, x, ld, out, M, N, accumulate);
   return LAUNCH_OK();
 }
 int vt_add_(float* a, const float* b, long n, vt_stream_t s) {
@@ -333,6 +364,25 @@ int vt_adamw(float* p, const float* g, float* m, float* v, long n, float lr, flo
   if (!p || !g || !m || !v || n < 1 || step < 1) return vt_fail(VT_ERR_ARG, "vt_adamw: bad argument");
   const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, g1(n), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2));
+  return LAUNCH_OK();
+}
+int vt_train_hyper(float lr, float beta1, float beta2, int step, float ema_decay, float* out4) {   // host: the scalars vt_adamw / vt_ema_update derive
+  if (!out4 || step < 1) return vt_fail(VT_ERR_ARG, "vt_train_hyper: bad argument");
+  out4[0] = lr;
+  out4[1] = 1.0f - powf(beta1, (float)step);
+  out4[2] = sqrtf(1.0f - powf(beta2, (float)step));
+  out4[3] = 1.0f - ema_decay;
+  return VT_OK;
+}
+int vt_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                 vt_stream_t s) {
+  if (!p || !g || !m || !v || !hyper || n < 1) return vt_fail(VT_ERR_ARG, "vt_adamw_dev: bad argument");
+  hipLaunchKernelGGL(adamw_dev_kernel, g1(n), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay);
+  return LAUNCH_OK();
+}
+int vt_ema_update_dev(float* shadow, const float* p, long n, const float* hyper, vt_stream_t s) {
+  if (!shadow || !p || !hyper || n < 1) return vt_fail(VT_ERR_ARG, "vt_ema_update_dev: bad argument");
+  hipLaunchKernelGGL(ema_dev_kernel, g1(n), dim3(256), 0, (hipStream_t)s, shadow, p, n, hyper);
   return LAUNCH_OK();
 }
 int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_t s) {

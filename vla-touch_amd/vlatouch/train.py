@@ -485,7 +485,8 @@ class SITrainer:
             for k in self.mlp.p:
                 yield f"state_encoder.{k}", self.mlp.p[k], self.mlp.g.get(k)
 
-    def get_loss(self, obs: torch.Tensor, vla_n: torch.Tensor, expert_n: torch.Tensor, t: torch.Tensor, z: torch.Tensor, *, backward: bool = True):
+    def get_loss(self, obs: torch.Tensor, vla_n: torch.Tensor, expert_n: torch.Tensor, t: torch.Tensor, z: torch.Tensor, *, backward: bool = True,
+                 sync: bool = True):
         """obs: `obs_cond` [B,256], or the observation MLP's input [B, 2*Dv+13] when the trainer owns the MLP; vla_n / expert_n
         [B,T,10] normalised source / target; t [B] in [0,1] (the reference's torch.rand draw); z [B,T,10] N(0,1) (scaled by beta_max
         here, as `interpolant` does) -> (loss, {'v_loss','s_loss','b_loss'}) as python floats; gradients are left in the nets."""
@@ -510,27 +511,73 @@ class SITrainer:
         if backward and self.mlp is not None:
             self.mlp.backward(dcond)
         self.last_dcond = dcond
+        if not sync:            # device tensors, no host read-back: what a captured (hipGraph) step returns
+            return None, losses
         vals = {k: float(v.item()) for k, v in losses.items()}
         return vals["v_loss"] + vals["s_loss"] + vals["b_loss"], vals
 
-    def optimizer_step(self):
-        """AdamW on every trained tensor, then the EMA update of the net parameters (bridge_train.py:331-334)."""
-        self.step_count += 1
+    def _ema_decay(self, step: int) -> float:
+        return min(self.ema_decay, (1 + step) / (10 + step))                                 # torch_ema's warm-up
+
+    def optimizer_step(self, hyper: Optional[torch.Tensor] = None):
+        """AdamW on every trained tensor, then the EMA update of the net parameters (bridge_train.py:331-334).  `hyper` (device,
+        [lr, 1-b1^t, sqrt(1-b2^t), 1-ema_decay_t]) selects the kernels that read the step-dependent scalars from memory (graph replay)."""
+        if hyper is None:
+            self.step_count += 1
         lib, dev = L.lib(), self.device
         for name, p, g in self._all_params():
             if g is None:
                 raise RuntimeError(f"no gradient for {name}: call get_loss first")
             if name not in self._m:
                 self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
-            L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
-                                 self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
-        decay = min(self.ema_decay, (1 + self.step_count) / (10 + self.step_count))          # torch_ema's warm-up
+            if hyper is None:
+                L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
+                                     self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
+            else:
+                L.check(lib.vt_adamw_dev(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), L.ptr(hyper),
+                                         self.betas[0], self.betas[1], self.eps, self.wd, _sp(dev)), "vt_adamw_dev")
         for name, sh in self.shadow.items():
             n, k = name.split(".", 1)
-            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), decay, _sp(dev)), "vt_ema_update")
+            if hyper is None:
+                L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
+            else:
+                L.check(lib.vt_ema_update_dev(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), L.ptr(hyper), _sp(dev)), "vt_ema_update_dev")
 
-    def train_step(self, obs, vla_n, expert_n, t, z):
-        loss, info = self.get_loss(obs, vla_n, expert_n, t, z)
+    # ---- the whole step as one hipGraph (the eager step is a ~3000-launch dependent chain issued from Python)
+    def capture(self, batch: int, horizon: int = 16, dim: int = 10) -> None:
+        """Record get_loss + backward + AdamW + EMA for a fixed batch shape into a hipGraph (torch.cuda.graph: stream capture of the
+        C-ABI launches on torch's current stream).  `replay()` copies the inputs into the static buffers, writes the 16 bytes of
+        step-dependent scalars and launches the graph; results are identical to the eager step's (same kernels, same order)."""
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        obs_dim = self.mlp.kin if self.mlp is not None else 256
+        self._st = dict(obs=z(batch, obs_dim), x0=z(batch, horizon, dim), x1=z(batch, horizon, dim), t=z(batch), z=z(batch, horizon, dim))
+        self._hyper = z(4)
+        self._hyper_host = torch.zeros(4, dtype=F32).pin_memory()
+        for name, p, _ in self._all_params():
+            if name not in self._m:
+                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            _, self._graph_losses = self.get_loss(self._st["obs"], self._st["x0"], self._st["x1"], self._st["t"], self._st["z"], sync=False)
+            self.optimizer_step(hyper=self._hyper)
+
+    def replay(self, obs, vla_n, expert_n, t, z):
+        """One captured training step -> {'v_loss','s_loss','b_loss'} device tensors (read them after a synchronize)."""
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("call capture(batch) first")
+        for k, v in (("obs", obs), ("x0", vla_n), ("x1", expert_n), ("t", t), ("z", z)):
+            self._st[k].copy_(torch.as_tensor(v).reshape(self._st[k].shape), non_blocking=True)
+        self.step_count += 1
+        L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.step_count),
+                                       L.ptr(self._hyper_host)), "vt_train_hyper")
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._graph.replay()
+        return self._graph_losses
+
+    def train_step(self, obs, vla_n, expert_n, t, z, *, sync: bool = True):
+        loss, info = self.get_loss(obs, vla_n, expert_n, t, z, sync=sync)
         self.optimizer_step()
         return loss, info
 
