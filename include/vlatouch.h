@@ -240,6 +240,7 @@ int vt_si_qsample(const float* x0, const float* x1, const float* z, const float*
                   float* target_b, float* t_clipped, int B, long per_sample, int gamma_type, float t_min, vt_stream_t stream);
 /* loss[0] = mean_b(0.5 |out_b|^2 - <target_b, out_b>), dout = (out - target) / B   (the three interpolant losses share this form) */
 int vt_si_loss(const float* out, const float* target, float* dout, float* loss, int B, long per_sample, vt_stream_t stream);
+int vt_slab_sum(const float* slabs, int S, long n, const float* bias, int N, float* out, vt_stream_t stream);  /* split-K partials [S][n] -> out[n] (+ bias[i % N]) */
 int vt_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
              int step, vt_stream_t stream);
 int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_t stream);

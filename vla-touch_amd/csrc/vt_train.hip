@@ -89,6 +89,19 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* __restrict__ 
   if (r == 0 && n < N) out[n] = accumulate ? out[n] + part[0][c] : part[0][c];
 }
 
+// out[i] = sum_s slabs[s][i] (+ bias[i % N]), slabs summed in order: the reduction of a split-K GEMM's fp32 partial products
+__global__ void slab_sum_kernel(const float* __restrict__ slabs, int S, long n, const float* __restrict__ bias, int N, float* __restrict__ out) {
+  const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = *reinterpret_cast<const float4*>(slabs + i);
+  for (int s = 1; s < S; ++s) {
+    const float4 b = *reinterpret_cast<const float4*>(slabs + (long)s * n + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  if (bias) { const int c = (int)(i % N); a.x += bias[c]; a.y += bias[c + 1]; a.z += bias[c + 2]; a.w += bias[c + 3]; }
+  *reinterpret_cast<float4*>(out + i) = a;
+}
+
 __global__ void add_kernel(float* __restrict__ a, const float* __restrict__ b, long n) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) a[i] += b[i];
@@ -314,6 +327,11 @@ int vt_wflip(const float* W, float* WT, int Cout, int taps, int Cin, vt_stream_t
 int vt_colsum(const float* x, long ld, float* out, int M, int N, int accumulate, vt_stream_t s) {
   if (!x || !out || M < 1 || N < 1) return vt_fail(VT_ERR_ARG, "vt_colsum: bad argument");
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(1024), 0, (hipStream_t)s, x, ld, out, M, N, accumulate);
+  return LAUNCH_OK();
+}
+int vt_slab_sum(const float* slabs, int S, long n, const float* bias, int N, float* out, vt_stream_t s) {
+  if (!slabs || !out || S < 1 || n < 4 || n % 4 || N < 4 || N % 4 || n % N) return vt_fail(VT_ERR_ARG, "vt_slab_sum: bad argument (n, N multiples of 4)");
+  hipLaunchKernelGGL(slab_sum_kernel, g1(n / 4), dim3(256), 0, (hipStream_t)s, slabs, S, n, bias, N, out);
   return LAUNCH_OK();
 }
 int vt_add_(float* a, const float* b, long n, vt_stream_t s) {

@@ -18,6 +18,8 @@ loop: a training step is a few thousand small launches (this is the f-4 row "bui
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -97,8 +99,47 @@ def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
     return out
 
 
+def _splits(M: int, N: int, K: int) -> int:
+    """Split-K factor for the fp32 64x64-tile GEMM: the backward pass is full of products with few output tiles and a long reduction
+    (weight gradients: [Cout, k*Cin] outputs reduced over B*T rows; the T=4 levels: 512-row activations against k*Cin = 2560..5120) —
+    one 4-wave block per tile leaves most of the 256 CUs idle and nothing to hide the staging latency behind.  Aim at >= 768 blocks."""
+    if N % 4 or os.environ.get("VLATOUCH_TRAIN_SPLITK", "1") == "0":
+        return 1
+    blocks = ((M + 63) // 64) * ((N + 63) // 64)
+    s = 1
+    while s < 16 and blocks * s < 768 and K // (2 * s) >= 128:
+        s *= 2
+    return s
+
+
+def _slab_sum(slabs: torch.Tensor, bias, shape) -> torch.Tensor:
+    S = slabs.shape[0]
+    out = _empty(shape, slabs.device)
+    L.check(L.lib().vt_slab_sum(L.ptr(slabs), S, out.numel(), L.ptr(bias), shape[-1], L.ptr(out), _sp(slabs.device)), "vt_slab_sum")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias=None) -> torch.Tensor:
+    """a [M,K] x w [N,K]^T (+ bias) in fp32, split along K when the output has too few tiles to fill the chip (deterministic reduce)."""
+    M, K = a.shape
+    N = w.shape[0]
+    s = _splits(M, N, K)
+    if s == 1:
+        return ops.gemm(a, w, bias)
+    return _slab_sum(ops.gemm(a, w, None, splitk=s), bias, (M, N))
+
+
+def conv(x, wp, b, *, taps, cin, tout, stride, off0):
+    B = x.shape[0]
+    N = wp.shape[0]
+    s = _splits(B * tout, N, taps * cin)
+    if s == 1:
+        return ops.conv1d_cl(x, wp, b, taps=taps, cin=cin, tout=tout, stride=stride, off0=off0)
+    return _slab_sum(ops.conv1d_cl(x, wp, None, taps=taps, cin=cin, tout=tout, stride=stride, off0=off0, splitk=s), b, (B, tout, N))
+
+
 def conv_fwd(x, wp, b, k, stride, pad, tout):
-    return ops.conv1d_cl(x, wp, b, taps=k, cin=x.shape[2], tout=tout, stride=stride, off0=-pad)
+    return conv(x, wp, b, taps=k, cin=x.shape[2], tout=tout, stride=stride, off0=-pad)
 
 
 def conv_bwd(x, wp, dy, k, stride, pad):
@@ -106,27 +147,27 @@ def conv_bwd(x, wp, dy, k, stride, pad):
     B, tin, cin = x.shape
     tout, cout = dy.shape[1], dy.shape[2]
     dy2 = dy.reshape(B * tout, cout)
-    dwp = ops.gemm(transpose(dy2), im2col_t(x, tout, k, stride, -pad))            # [Cout, M] x [k*Cin, M]^T
+    dwp = gemm(transpose(dy2), im2col_t(x, tout, k, stride, -pad))            # [Cout, M] x [k*Cin, M]^T
     db = colsum(dy2)
     wt = wflip(wp, cout, k, cin)                                                  # [Cin, k*Cout], taps reversed
     src = dy if stride == 1 else zero_stuff(dy)                                   # strided conv: its data gradient is a transposed conv
-    dx = ops.conv1d_cl(src, wt, None, taps=k, cin=cout, tout=tin, stride=1, off0=pad - (k - 1))
+    dx = conv(src, wt, None, taps=k, cin=cout, tout=tin, stride=1, off0=pad - (k - 1))
     return dx, dwp, db
 
 
 def convT_fwd(x, wc, b):
     """ConvTranspose1d(k=4, s=2, p=1) as the stride-1 conv of the zero-stuffed input with wc[co][tp][ci] = W[ci][co][3 - tp]."""
     xz = zero_stuff(x)
-    return ops.conv1d_cl(xz, wc, b, taps=4, cin=x.shape[2], tout=2 * x.shape[1], stride=1, off0=-2), xz
+    return conv(xz, wc, b, taps=4, cin=x.shape[2], tout=2 * x.shape[1], stride=1, off0=-2), xz
 
 
 def convT_bwd(xz, wc, dy, cin):
     B, t2, cout = dy.shape
     dy2 = dy.reshape(B * t2, cout)
-    dwc = ops.gemm(transpose(dy2), im2col_t(xz, t2, 4, 1, -2))
+    dwc = gemm(transpose(dy2), im2col_t(xz, t2, 4, 1, -2))
     db = colsum(dy2)
     wt = wflip(wc, cout, 4, cin)
-    dx = ops.conv1d_cl(dy, wt, None, taps=4, cin=cout, tout=t2 // 2, stride=2, off0=-1)    # d xz at the even (non-stuffed) positions
+    dx = conv(dy, wt, None, taps=4, cin=cout, tout=t2 // 2, stride=2, off0=-1)    # d xz at the even (non-stuffed) positions
     return dx, dwc, db
 
 
@@ -149,7 +190,7 @@ def gn_bwd(c, gamma, beta, film, dout):
 
 def linear_bwd(x, w, dy):
     """y = x w^T + b: -> dx, dw, db."""
-    return ops.gemm(dy, transpose(w)), ops.gemm(transpose(dy), transpose(x)), colsum(dy)
+    return gemm(dy, transpose(w)), gemm(transpose(dy), transpose(x)), colsum(dy)
 
 
 # ---------------------------------------------------------------------------------------------- the U-Net
@@ -289,14 +330,14 @@ class TrainUNet:
             raise ValueError("TrainUNet: T must be a multiple of 4 and B*T/4 a multiple of 16")
         pe = _empty((B, 256), dev)
         L.check(L.lib().vt_posemb(L.ptr(t), L.ptr(pe), B, 256, _sp(dev)), "vt_posemb")
-        h1 = ops.gemm(pe, p["t1.w"], p["t1.b"])
+        h1 = gemm(pe, p["t1.w"], p["t1.b"])
         h1m = mish(h1)
-        temb = ops.gemm(h1m, p["t2.w"], p["t2.b"])
+        temb = gemm(h1m, p["t2.w"], p["t2.b"])
         gfeat = _empty((B, 512), dev)
         copy_cols(temb, 0, gfeat, 0, 256)
         copy_cols(cond, 0, gfeat, 256, 256)
         gm = mish(gfeat)
-        film_all = ops.gemm(gm, p["film.w"], p["film.b"])                       # [B, 10752]
+        film_all = gemm(gm, p["film.w"], p["film.b"])                       # [B, 10752]
         films, off = [], 0
         for (cin, cout) in RB_DIMS:
             fl = _empty((B, 2 * cout), dev)
@@ -431,7 +472,7 @@ class TrainMLP:
         copy_cols(x, 0, h, 0, self.kin)
         tape = []
         for n, i in enumerate(self.idx):
-            a = ops.gemm(h, self.p[f"{i}.weight"], self.p[f"{i}.bias"])
+            a = gemm(h, self.p[f"{i}.weight"], self.p[f"{i}.bias"])
             tape.append((h, a))
             h = gelu(a) if n + 1 < len(self.idx) else a
         self._tape = tape
@@ -655,7 +696,7 @@ class LstmTrainer:
         H, dev, lib, sp = self.H, self.device, L.lib(), _sp(self.device)
         bias = self.lstm[f"bias_ih_l{l}"].clone()                               # b_ih + b_hh folded into the all-tick input projection
         add_(bias, self.lstm[f"bias_hh_l{l}"])
-        gx = ops.gemm(X, self.lstm[f"weight_ih_l{l}"], bias)                  # [B*T, 4H], every tick at once
+        gx = gemm(X, self.lstm[f"weight_ih_l{l}"], bias)                  # [B*T, 4H], every tick at once
         act, cseq = _empty((B * T, 4 * H), dev), _empty((B * T, H), dev)
         hseq, hprev, hcur = _empty((B * T, H), dev), _empty((B * T, H), dev), _empty((B, H), dev)
         gh = None
@@ -678,7 +719,7 @@ class LstmTrainer:
             if t > 0:
                 dh_rec = ops.gemm(dgcur, whh_t)
         dX, self.gl[f"weight_ih_l{l}"], db = linear_bwd(X, self.lstm[f"weight_ih_l{l}"], dgates)
-        self.gl[f"weight_hh_l{l}"] = ops.gemm(transpose(dgates), transpose(hprev))
+        self.gl[f"weight_hh_l{l}"] = gemm(transpose(dgates), transpose(hprev))
         self.gl[f"bias_ih_l{l}"], self.gl[f"bias_hh_l{l}"] = db, db
         return dX
 
@@ -719,7 +760,7 @@ class LstmTrainer:
         comb = _empty((M, 2 * H), dev)
         copy_cols(hseq, 0, comb, 0, H)
         L.check(lib.vt_bcast_mid(L.ptr(cond), L.ptr(comb), 2 * H, H, B, T, H, sp), "vt_bcast_mid")
-        a1 = ops.gemm(comb, self.head["0.weight"], self.head["0.bias"])
+        a1 = gemm(comb, self.head["0.weight"], self.head["0.bias"])
         n1 = ops.rownorm(a1, self.head["1.weight"], self.head["1.bias"], 1e-5)
         g1_ = gelu(n1)
         hm = self._mask(masks, "head", (M, H), self.p_head)
@@ -734,7 +775,7 @@ class LstmTrainer:
             copy_cols(ddelta, 0, ddp, 0, D)
             copy_cols(self.head["4.weight"], 0, w4p, 0, H)
             dg1 = ops.gemm(ddp, transpose(w4p))
-            self.gh["4.weight"], self.gh["4.bias"] = ops.gemm(transpose(ddelta), transpose(g1_)), colsum(ddelta)
+            self.gh["4.weight"], self.gh["4.bias"] = gemm(transpose(ddelta), transpose(g1_)), colsum(ddelta)
             if hm is not None:
                 L.check(lib.vt_mul_(L.ptr(dg1), L.ptr(hm), dg1.numel(), sp), "vt_mul_")
             dn1 = gelu(n1, dg1)
