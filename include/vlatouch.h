@@ -249,6 +249,11 @@ int vt_ema_update(float* shadow, const float* p, long n, float decay, vt_stream_
 int vt_train_hyper(float lr, float beta1, float beta2, int step, float ema_decay, float* out4_host);   /* host-side: fills hyper for step t */
 int vt_adamw_dev(float* p, const float* g, float* m, float* v, long n, const float* hyper, float beta1, float beta2, float eps,
                  float weight_decay, vt_stream_t stream);
+/* AdamW (+ EMA) over a device table of tensors in ONE launch.  table = ntensors records of 7 x 8 bytes:
+ * {float* p, const float* g, float* m, float* v, float* shadow_or_null, int64 n, int64 first_chunk}, first_chunk = running sum of
+ * ceil(n / 4096) over the preceding records; total_chunks = that sum over all records.  hyper as vt_adamw_dev. */
+int vt_adamw_ema_multi(const void* table, int ntensors, long total_chunks, const float* hyper, float beta1, float beta2, float eps,
+                       float weight_decay, vt_stream_t stream);
 int vt_ema_update_dev(float* shadow, const float* p, long n, const float* hyper, vt_stream_t stream);
 int vt_posemb(const float* t, float* out, int B, int dim, vt_stream_t stream);                    /* SinusoidalPosEmb: [sin | cos] */
 

@@ -251,18 +251,29 @@ __global__ __launch_bounds__(256) void si_loss_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) loss[0] = ((red[0] + red[1]) + (red[2] + red[3])) * invB;
 }
 
+// One element of torch.optim.AdamW / torch_ema.  Contraction is switched off so that the three kernels below (scalar arguments, scalars from
+// device memory, multi-tensor table) round identically: a replayed graph and the eager step then agree bit for bit.
+__device__ __forceinline__ float adamw_elem(float p, float gv, float& m, float& v, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt) {
+#pragma clang fp contract(off)
+  const float pv = p * (1.0f - lr * wd);
+  const float mv = b1 * m + (1.0f - b1) * gv;
+  const float vv = b2 * v + (1.0f - b2) * gv * gv;
+  m = mv; v = vv;
+  const float denom = sqrtf(vv) / bc2_sqrt + eps;
+  return pv - (lr / bc1) * (mv / denom);
+}
+__device__ __forceinline__ float ema_elem(float sh, float p, float one_minus_decay) {
+#pragma clang fp contract(off)
+  return sh - one_minus_decay * (sh - p);
+}
 // torch.optim.AdamW (decoupled weight decay, bias-corrected moments), one fused pass
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n, float lr, float b1, float b2,
                              float eps, float wd, float bc1, float bc2_sqrt) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  float pv = p[i] * (1.0f - lr * wd);
-  const float gv = g[i];
-  const float mv = b1 * m[i] + (1.0f - b1) * gv;
-  const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+  float mv = m[i], vv = v[i];
+  p[i] = adamw_elem(p[i], g[i], mv, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
   m[i] = mv; v[i] = vv;
-  const float denom = sqrtf(vv) / bc2_sqrt + eps;
-  p[i] = pv - (lr / bc1) * (mv / denom);
 }
 // the same update with the step-dependent scalars read from device memory (hyper = [lr, 1 - beta1^t, sqrt(1 - beta2^t), 1 - ema_decay_t]),
 // so that a captured hipGraph of the step can be replayed while the step count advances
@@ -271,22 +282,42 @@ __global__ void adamw_dev_kernel(float* __restrict__ p, const float* __restrict_
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
-  float pv = p[i] * (1.0f - lr * wd);
-  const float gv = g[i];
-  const float mv = b1 * m[i] + (1.0f - b1) * gv;
-  const float vv = b2 * v[i] + (1.0f - b2) * gv * gv;
+  float mv = m[i], vv = v[i];
+  p[i] = adamw_elem(p[i], g[i], mv, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
   m[i] = mv; v[i] = vv;
-  const float denom = sqrtf(vv) / bc2_sqrt + eps;
-  p[i] = pv - (lr / bc1) * (mv / denom);
 }
 __global__ void ema_dev_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, const float* __restrict__ hyper) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) shadow[i] -= hyper[3] * (shadow[i] - p[i]);
+  if (i < n) shadow[i] = ema_elem(shadow[i], p[i], hyper[3]);
 }
+// AdamW (+ EMA where the tensor has a shadow) over a TABLE of tensors in one launch: a training step updates ~380 tensors, most of them
+// a few KB, and one launch each is launch-gap-bound.  tab[k] = {p, g, m, v, shadow | null, n, first_chunk}; a block takes one 4096-
+// element chunk and finds its tensor by binary search over first_chunk.  Arithmetic identical to adamw_dev_kernel / ema_dev_kernel.
+struct MtEntry { float* p; const float* g; float* m; float* v; float* shadow; long n; long first_chunk; };
+__global__ __launch_bounds__(256) void adamw_ema_mt_kernel(const MtEntry* __restrict__ tab, int ntensors, const float* __restrict__ hyper,
+                                                           float b1, float b2, float eps, float wd) {
+  int lo = 0, hi = ntensors - 1;
+  const long chunk = blockIdx.x;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (tab[mid].first_chunk <= chunk) lo = mid; else hi = mid - 1; }
+  const MtEntry e = tab[lo];
+  const long base = (chunk - e.first_chunk) * 4096;
+  const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2], omd = hyper[3];
+#pragma unroll 4
+  for (int it = 0; it < 16; ++it) {
+    const long i = base + it * 256 + threadIdx.x;
+    if (i >= e.n) break;
+    float mv = e.m[i], vv = e.v[i];
+    const float pv = adamw_elem(e.p[i], e.g[i], mv, vv, lr, b1, b2, eps, wd, bc1, bc2_sqrt);
+    e.m[i] = mv; e.v[i] = vv;
+    e.p[i] = pv;
+    if (e.shadow) e.shadow[i] = ema_elem(e.shadow[i], pv, omd);
+  }
+}
+
 // torch_ema: shadow -= (1 - decay) * (shadow - p)
 __global__ void ema_kernel(float* __restrict__ shadow, const float* __restrict__ p, long n, float one_minus_decay) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) shadow[i] -= one_minus_decay * (shadow[i] - p[i]);
+  if (i < n) shadow[i] = ema_elem(shadow[i], p[i], one_minus_decay);
 }
 // SinusoidalPosEmb (conditional_unet_1D.py:7-19): emb[b] = [sin(t_b f_j) | cos(t_b f_j)], f_j = exp(-j log(10000) / (half - 1))
 __global__ void posemb_kernel(const float* __restrict__ t, float* __restrict__ out, int B, int dim) {
@@ -396,6 +427,13 @@ int vt_adamw_dev(float* p, const float* g, float* m, float* v, long n, const flo
                  vt_stream_t s) {
   if (!p || !g || !m || !v || !hyper || n < 1) return vt_fail(VT_ERR_ARG, "vt_adamw_dev: bad argument");
   hipLaunchKernelGGL(adamw_dev_kernel, g1(n), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, hyper, beta1, beta2, eps, weight_decay);
+  return LAUNCH_OK();
+}
+int vt_adamw_ema_multi(const void* table, int ntensors, long total_chunks, const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                       vt_stream_t s) {
+  if (!table || !hyper || ntensors < 1 || total_chunks < 1) return vt_fail(VT_ERR_ARG, "vt_adamw_ema_multi: bad argument");
+  hipLaunchKernelGGL(adamw_ema_mt_kernel, dim3((unsigned)total_chunks), dim3(256), 0, (hipStream_t)s, (const MtEntry*)table, ntensors, hyper, beta1, beta2,
+                     eps, weight_decay);
   return LAUNCH_OK();
 }
 int vt_ema_update_dev(float* shadow, const float* p, long n, const float* hyper, vt_stream_t s) {

@@ -165,6 +165,7 @@ SIGNATURES = {
     "vt_ema_update": (_I, [_P, _P, _L, _F, _P]),
     "vt_train_hyper": (_I, [_F, _F, _F, _I, _F, _P]),
     "vt_adamw_dev": (_I, [_P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _P]),
+    "vt_adamw_ema_multi": (_I, [_P, _I, _L, _P, _F, _F, _F, _F, _P]),
     "vt_ema_update_dev": (_I, [_P, _P, _L, _P, _P]),
     "vt_posemb": (_I, [_P, _P, _I, _I, _P]),
     "vt_lstm_cell_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -574,15 +574,22 @@ class SITrainer:
             if hyper is None:
                 L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
                                      self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
-            else:
-                L.check(lib.vt_adamw_dev(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), L.ptr(hyper),
-                                         self.betas[0], self.betas[1], self.eps, self.wd, _sp(dev)), "vt_adamw_dev")
+        if hyper is not None:       # graph path: every tensor's AdamW (+ EMA) in one launch over a device table of pointers
+            rows, chunk0 = [], 0
+            for name, p, g in self._all_params():
+                assert g.is_contiguous() and p.is_contiguous()
+                sh = self.shadow.get(name)
+                rows.append([p.data_ptr(), g.data_ptr(), self._m[name].data_ptr(), self._v[name].data_ptr(), 0 if sh is None else sh.data_ptr(),
+                             p.numel(), chunk0])
+                chunk0 += (p.numel() + 4095) // 4096
+            self._mt_host.copy_(torch.tensor(rows, dtype=torch.int64))          # pinned, allocated by capture() before the capture began
+            self._mt_dev.copy_(self._mt_host, non_blocking=True)
+            L.check(lib.vt_adamw_ema_multi(L.ptr(self._mt_dev), len(rows), chunk0, L.ptr(hyper), self.betas[0], self.betas[1], self.eps, self.wd,
+                                           _sp(dev)), "vt_adamw_ema_multi")
+            return
         for name, sh in self.shadow.items():
             n, k = name.split(".", 1)
-            if hyper is None:
-                L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
-            else:
-                L.check(lib.vt_ema_update_dev(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), L.ptr(hyper), _sp(dev)), "vt_ema_update_dev")
+            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
 
     # ---- the whole step as one hipGraph (the eager step is a ~3000-launch dependent chain issued from Python)
     def capture(self, batch: int, horizon: int = 16, dim: int = 10) -> None:
@@ -598,6 +605,9 @@ class SITrainer:
         for name, p, _ in self._all_params():
             if name not in self._m:
                 self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+        ntens = sum(1 for _ in self._all_params())
+        self._mt_host = torch.zeros(ntens, 7, dtype=torch.int64).pin_memory()
+        self._mt_dev = torch.zeros(ntens, 7, dtype=torch.int64, device=dev)
         torch.cuda.synchronize(dev)
         self._graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._graph):
