@@ -270,3 +270,28 @@ def test_captured_training_step_equals_eager():
     ea, eb = a.ema_state_dict(), b.ema_state_dict()
     assert all(torch.equal(ea[k], eb[k]) for k in ea)
     assert all(torch.equal(x, y) for x, y in zip(a.mlp.state_dict().values(), b.mlp.state_dict().values()))
+
+
+def test_captured_lstm_training_step_equals_eager():
+    from vlatouch.train import LstmTrainer
+    from tools.make_golden_train_lstm import lstm_train_inputs
+    a, b = LstmTrainer(cases.lstm_mods(), lr=1e-3, device="cuda:0"), LstmTrainer(cases.lstm_mods(), lr=1e-3, device="cuda:0")
+    b.capture(16, masks=None)
+    for step in (1, 2, 3):
+        inp = lstm_train_inputs(step)
+        args = [inp[k].to("cuda:0") for k in ("obs_in", "vla_n", "forces", "expert_n")]
+        la = a.train_step(*args, masks=None)
+        lb = b.replay(*args)
+        torch.cuda.synchronize()
+        assert float(lb) == la, (step, la, float(lb))
+    sa, sb = a.modules_state_dict(), b.modules_state_dict()
+    assert all(torch.equal(sa[m][k], sb[m][k]) for m in sa for k in sa[m])
+    b2 = LstmTrainer(cases.lstm_mods(), device="cuda:0")
+    b2.capture(16)                                           # masks drawn inside the graph: a fresh draw per replay
+    args = [lstm_train_inputs(1)[k].to("cuda:0") for k in ("obs_in", "vla_n", "forces", "expert_n")]
+    l1 = float(b2.replay(*args, schedule=False)); p1 = b2._graph_pred.clone()
+    b3 = LstmTrainer(cases.lstm_mods(), device="cuda:0")
+    b3.capture(16)
+    l2 = float(b3.replay(*args, schedule=False))
+    torch.cuda.synchronize()
+    assert np.isfinite([l1, l2]).all() and l1 != l2 and not torch.equal(p1, b3._graph_pred)      # same weights and inputs, different masks

@@ -495,7 +495,75 @@ class TrainMLP:
 _GAMMA = {"2^0.5*t(t-1)": 0, "(2t(t-1))^0.5": 1, "(1-t)^2(2t)^0.5": 2}
 
 
-class SITrainer:
+class _Optimizer:
+    """AdamW (+ EMA shadows) over the tensors a trainer yields from `_all_params()`, eager or inside a captured graph."""
+    ema_decay = 0.0
+    shadow: Dict[str, torch.Tensor] = {}
+
+    def _ema_decay(self, step: int) -> float:
+        return min(self.ema_decay, (1 + step) / (10 + step))                                 # torch_ema's warm-up
+
+    def _shadow_source(self, name: str) -> torch.Tensor:
+        raise NotImplementedError
+
+    def optimizer_step(self, hyper: Optional[torch.Tensor] = None):
+        """AdamW on every trained tensor, then the EMA update of the net parameters (bridge_train.py:331-334).  `hyper` (device,
+        [lr, 1-b1^t, sqrt(1-b2^t), 1-ema_decay_t]) selects the kernels that read the step-dependent scalars from memory (graph replay)."""
+        if hyper is None:
+            self.step_count += 1
+        lib, dev = L.lib(), self.device
+        for name, p, g in self._all_params():
+            if g is None:
+                raise RuntimeError(f"no gradient for {name}: call get_loss first")
+            if name not in self._m:
+                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+            if hyper is None:
+                L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
+                                     self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
+        if hyper is not None:       # graph path: every tensor's AdamW (+ EMA) in one launch over a device table of pointers
+            rows, chunk0 = [], 0
+            for name, p, g in self._all_params():
+                assert g.is_contiguous() and p.is_contiguous()
+                sh = self.shadow.get(name)
+                rows.append([p.data_ptr(), g.data_ptr(), self._m[name].data_ptr(), self._v[name].data_ptr(), 0 if sh is None else sh.data_ptr(),
+                             p.numel(), chunk0])
+                chunk0 += (p.numel() + 4095) // 4096
+            self._mt_host.copy_(torch.tensor(rows, dtype=torch.int64))          # pinned, allocated by _capture_prep() before the capture began
+            self._mt_dev.copy_(self._mt_host, non_blocking=True)
+            L.check(lib.vt_adamw_ema_multi(L.ptr(self._mt_dev), len(rows), chunk0, L.ptr(hyper), self.betas[0], self.betas[1], self.eps, self.wd,
+                                           _sp(dev)), "vt_adamw_ema_multi")
+            return
+        for name, sh in self.shadow.items():
+            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self._shadow_source(name)), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
+
+    # ---- the whole step as one hipGraph (the eager step is a dependent chain of hundreds to thousands of launches issued from Python)
+    def _capture_prep(self, **static: torch.Tensor) -> None:
+        dev = self.device
+        self._st = static
+        self._hyper = torch.zeros(4, dtype=F32, device=dev)
+        self._hyper_host = torch.zeros(4, dtype=F32).pin_memory()
+        for name, p, _ in self._all_params():
+            if name not in self._m:
+                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
+        ntens = sum(1 for _ in self._all_params())
+        self._mt_host = torch.zeros(ntens, 7, dtype=torch.int64).pin_memory()
+        self._mt_dev = torch.zeros(ntens, 7, dtype=torch.int64, device=dev)
+        torch.cuda.synchronize(dev)
+        self._graph = torch.cuda.CUDAGraph()
+
+    def _replay(self, **inputs) -> None:
+        if getattr(self, "_graph", None) is None:
+            raise RuntimeError("call capture(...) first")
+        for k, v in inputs.items():
+            self._st[k].copy_(torch.as_tensor(v).reshape(self._st[k].shape), non_blocking=True)
+        self.step_count += 1
+        L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.step_count),
+                                       L.ptr(self._hyper_host)), "vt_train_hyper")
+        self._hyper.copy_(self._hyper_host, non_blocking=True)
+        self._graph.replay()
+
+
+class SITrainer(_Optimizer):
     """get_loss + backward + AdamW + EMA for `StochasticInterpolants` (+ the observation MLP), one step per `train_step` call.
 
     net_sd: the reference's `InterpolantsConditionalUnet1D` state dict (keys 'v_net.*', 's_net.*', 'b_net.*'); mlp_sd: state_encoder's.
@@ -557,74 +625,24 @@ class SITrainer:
         vals = {k: float(v.item()) for k, v in losses.items()}
         return vals["v_loss"] + vals["s_loss"] + vals["b_loss"], vals
 
-    def _ema_decay(self, step: int) -> float:
-        return min(self.ema_decay, (1 + step) / (10 + step))                                 # torch_ema's warm-up
+    def _shadow_source(self, name: str) -> torch.Tensor:
+        n, k = name.split(".", 1)
+        return self.nets[n].p[k]
 
-    def optimizer_step(self, hyper: Optional[torch.Tensor] = None):
-        """AdamW on every trained tensor, then the EMA update of the net parameters (bridge_train.py:331-334).  `hyper` (device,
-        [lr, 1-b1^t, sqrt(1-b2^t), 1-ema_decay_t]) selects the kernels that read the step-dependent scalars from memory (graph replay)."""
-        if hyper is None:
-            self.step_count += 1
-        lib, dev = L.lib(), self.device
-        for name, p, g in self._all_params():
-            if g is None:
-                raise RuntimeError(f"no gradient for {name}: call get_loss first")
-            if name not in self._m:
-                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
-            if hyper is None:
-                L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
-                                     self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
-        if hyper is not None:       # graph path: every tensor's AdamW (+ EMA) in one launch over a device table of pointers
-            rows, chunk0 = [], 0
-            for name, p, g in self._all_params():
-                assert g.is_contiguous() and p.is_contiguous()
-                sh = self.shadow.get(name)
-                rows.append([p.data_ptr(), g.data_ptr(), self._m[name].data_ptr(), self._v[name].data_ptr(), 0 if sh is None else sh.data_ptr(),
-                             p.numel(), chunk0])
-                chunk0 += (p.numel() + 4095) // 4096
-            self._mt_host.copy_(torch.tensor(rows, dtype=torch.int64))          # pinned, allocated by capture() before the capture began
-            self._mt_dev.copy_(self._mt_host, non_blocking=True)
-            L.check(lib.vt_adamw_ema_multi(L.ptr(self._mt_dev), len(rows), chunk0, L.ptr(hyper), self.betas[0], self.betas[1], self.eps, self.wd,
-                                           _sp(dev)), "vt_adamw_ema_multi")
-            return
-        for name, sh in self.shadow.items():
-            n, k = name.split(".", 1)
-            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self.nets[n].p[k]), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
-
-    # ---- the whole step as one hipGraph (the eager step is a ~3000-launch dependent chain issued from Python)
     def capture(self, batch: int, horizon: int = 16, dim: int = 10) -> None:
         """Record get_loss + backward + AdamW + EMA for a fixed batch shape into a hipGraph (torch.cuda.graph: stream capture of the
         C-ABI launches on torch's current stream).  `replay()` copies the inputs into the static buffers, writes the 16 bytes of
         step-dependent scalars and launches the graph; results are identical to the eager step's (same kernels, same order)."""
-        dev = self.device
-        z = lambda *s: torch.zeros(*s, dtype=F32, device=dev)
+        z = lambda *s: torch.zeros(*s, dtype=F32, device=self.device)
         obs_dim = self.mlp.kin if self.mlp is not None else 256
-        self._st = dict(obs=z(batch, obs_dim), x0=z(batch, horizon, dim), x1=z(batch, horizon, dim), t=z(batch), z=z(batch, horizon, dim))
-        self._hyper = z(4)
-        self._hyper_host = torch.zeros(4, dtype=F32).pin_memory()
-        for name, p, _ in self._all_params():
-            if name not in self._m:
-                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
-        ntens = sum(1 for _ in self._all_params())
-        self._mt_host = torch.zeros(ntens, 7, dtype=torch.int64).pin_memory()
-        self._mt_dev = torch.zeros(ntens, 7, dtype=torch.int64, device=dev)
-        torch.cuda.synchronize(dev)
-        self._graph = torch.cuda.CUDAGraph()
+        self._capture_prep(obs=z(batch, obs_dim), x0=z(batch, horizon, dim), x1=z(batch, horizon, dim), t=z(batch), z=z(batch, horizon, dim))
         with torch.cuda.graph(self._graph):
             _, self._graph_losses = self.get_loss(self._st["obs"], self._st["x0"], self._st["x1"], self._st["t"], self._st["z"], sync=False)
             self.optimizer_step(hyper=self._hyper)
 
     def replay(self, obs, vla_n, expert_n, t, z):
         """One captured training step -> {'v_loss','s_loss','b_loss'} device tensors (read them after a synchronize)."""
-        if getattr(self, "_graph", None) is None:
-            raise RuntimeError("call capture(batch) first")
-        for k, v in (("obs", obs), ("x0", vla_n), ("x1", expert_n), ("t", t), ("z", z)):
-            self._st[k].copy_(torch.as_tensor(v).reshape(self._st[k].shape), non_blocking=True)
-        self.step_count += 1
-        L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.step_count),
-                                       L.ptr(self._hyper_host)), "vt_train_hyper")
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
-        self._graph.replay()
+        self._replay(obs=obs, x0=vla_n, x1=expert_n, t=t, z=z)
         return self._graph_losses
 
     def train_step(self, obs, vla_n, expert_n, t, z, *, sync: bool = True):
@@ -662,7 +680,7 @@ def _cosine_lr(base: float, step: int, t_max: int = 100000) -> float:
     return eta + (base - eta) * (1 + math.cos(math.pi * step / t_max)) / 2
 
 
-class LstmTrainer:
+class LstmTrainer(_Optimizer):
     """forward + get_loss + BPTT + AdamW for `TactileLSTMController` (lstm_step_controller.py:176-211, 321-337; lstm_train.py:26-33,
     129-133).  `mods` = the checkpoint's 'modules' dict: obs_encoder / force_encoder (nn.Sequential MLPs), lstm (torch.nn.LSTM keys
     weight_ih_l{k}, weight_hh_l{k}, bias_ih_l{k}, bias_hh_l{k}), output_head (0 Linear, 1 LayerNorm, 4 Linear).
@@ -743,7 +761,7 @@ class LstmTrainer:
         m = masks.get(key)
         return None if m is None else m.to(self.device, F32).contiguous().reshape(shape)
 
-    def get_loss(self, obs, vla_n, forces, expert_n, *, masks=None, backward: bool = True):
+    def get_loss(self, obs, vla_n, forces, expert_n, *, masks=None, backward: bool = True, sync: bool = True):
         """obs: obs_cond [B,H], or the obs_encoder's input [B, 2*Dv+state] when the trainer owns that MLP; vla_n / expert_n [B,T,D]
         normalised; forces [B,T,F] -> (loss, pred [B,T,D]); gradients are left in the trainer."""
         dev, lib, sp, H = self.device, L.lib(), _sp(self.device), self.H
@@ -809,7 +827,7 @@ class LstmTrainer:
             if self.obs is not None:
                 self.obs.backward(dcond)
             self.last_dcond = dcond
-        return float(loss.item()), pred.reshape(B, T, D)
+        return (float(loss.item()) if sync else loss), pred.reshape(B, T, D)
 
     # ---- parameters in the reference's layout
     def _all(self):
@@ -846,16 +864,25 @@ class LstmTrainer:
             out["obs_encoder"] = self.obs.grads()
         return out
 
-    def optimizer_step(self):
-        self.step_count += 1
-        lib, dev = L.lib(), self.device
-        for name, p, g in self._all():
-            if g is None:
-                raise RuntimeError(f"no gradient for {name}: call get_loss first")
-            if name not in self._m:
-                self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
-            L.check(lib.vt_adamw(L.ptr(p), L.ptr(g.contiguous()), L.ptr(self._m[name]), L.ptr(self._v[name]), p.numel(), self.lr, self.betas[0],
-                                 self.betas[1], self.eps, self.wd, self.step_count, _sp(dev)), "vt_adamw")
+    def _all_params(self):
+        return self._all()
+
+    def capture(self, batch: int, horizon: int = 16, dim: int = 10, masks="draw") -> None:
+        """One training step (get_loss with device-drawn dropout masks, BPTT, AdamW) as a hipGraph for a fixed batch shape."""
+        z = lambda *s: torch.zeros(*s, dtype=F32, device=self.device)
+        obs_dim = self.obs.kin if self.obs is not None else self.H
+        self._capture_prep(obs=z(batch, obs_dim), vla=z(batch, horizon, dim), forces=z(batch, horizon, self.force.kin), expert=z(batch, horizon, dim))
+        with torch.cuda.graph(self._graph):
+            self._graph_loss, self._graph_pred = self.get_loss(self._st["obs"], self._st["vla"], self._st["forces"], self._st["expert"], masks=masks,
+                                                               sync=False)
+            self.optimizer_step(hyper=self._hyper)
+
+    def replay(self, obs, vla_n, forces, expert_n, *, schedule: bool = True):
+        """-> the loss as a 1-element device tensor (read it after a synchronize)."""
+        if schedule:
+            self.lr = _cosine_lr(self.base_lr, self.step_count)
+        self._replay(obs=obs, vla=vla_n, forces=forces, expert=expert_n)
+        return self._graph_loss
 
     def train_step(self, obs, vla_n, forces, expert_n, *, masks="draw", schedule: bool = True):
         if schedule:
