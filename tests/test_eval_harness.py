@@ -103,3 +103,37 @@ def test_refine_episode_is_the_batch_path_over_one_episode():
     verr = torch.mean((torch.cat(vlas) - torch.cat(exps)) ** 2).item()
     assert abs(met["error"] - err) < 1e-9 and abs(met["vla_error"] - verr) < 1e-9
     assert abs(met["improvement"] - (1 - err / verr) * 100) < 1e-6
+
+
+def test_controller_dataset_and_data_module_mirrors():
+    """residual_controller.controller_dataset.ControllerDataset / ControllerDataModule over the h5 episode fixtures: the index mapping,
+    samples and statistics the REFERENCE class produced on the same two episodes (g10), and the file-level train / val split."""
+    from residual_controller.controller_dataset import ControllerDataModule, ControllerDataset
+    g = G()
+    root = os.path.join(cases.GOLDEN, "episodes_h5")
+    files = [os.path.join(root, f) for f in ("episode_1.h5", "episode_2.h5")]
+    ds = ControllerDataset(root, file_paths=files, context_frames=2, horizon=16, use_images=True)
+    assert len(ds) == len(g["episode_indices"]) and np.array_equal(np.array(ds.episode_indices), g["episode_indices"])
+    for k, v in ds.stats.items():
+        assert np.abs(v - g["stats_" + k]).max() < 1e-9, k
+    for idx in (0, 3, len(ds) - 1):
+        smp = ds[idx]
+        for k in ("states", "vla_actions", "expert_actions", "forces", "disps"):
+            assert np.abs(smp[k].numpy() - g[f"s{idx}_{k}"]).max() < 1e-6, (idx, k)
+        assert smp["images_cam1"].shape == (2, 28, 28, 3) and float(smp["images_cam1"].max()) <= 1.0
+    np.random.seed(0)
+    import tempfile, shutil
+    with tempfile.TemporaryDirectory() as d:           # only the two episode files (storage_forms.h5 in the fixture dir is not an episode)
+        for f in files:
+            shutil.copy(f, d)
+        dm = ControllerDataModule(d, batch_size=8, num_workers=0, context_frames=2, horizon=16, use_images=True, val_ratio=0.1)
+        assert len(dm.train_dataset.file_paths) == 1 and len(dm.val_dataset.file_paths) == 1
+        assert set(dm.train_dataset.file_paths) | set(dm.val_dataset.file_paths) == {os.path.join(d, os.path.basename(f)) for f in files}
+        tb = list(dm.train_dataloader())
+        assert len(tb) == len(dm.train_dataset) // 8 and all(b["states"].shape == (8, 18, 10) for b in tb)      # drop_last
+        vb = list(dm.val_dataloader())
+        assert sum(b["states"].shape[0] for b in vb) == len(dm.val_dataset)
+        assert vb[0]["images_cam1"].shape[1:] == (2, 28, 28, 3) and vb[0]["vla_actions"].shape[1:] == (16, 10)
+        one = ControllerDataset(d, file_paths=dm.train_dataset.file_paths, context_frames=2, horizon=16)
+        for k, v in dm.stats.items():
+            assert np.array_equal(v, one.stats[k])

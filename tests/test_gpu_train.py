@@ -295,3 +295,62 @@ def test_captured_lstm_training_step_equals_eager():
     l2 = float(b3.replay(*args, schedule=False))
     torch.cuda.synchronize()
     assert np.isfinite([l1, l2]).all() and l1 != l2 and not torch.equal(p1, b3._graph_pred)      # same weights and inputs, different masks
+
+
+def test_trainer_runs_an_epoch_from_h5_episodes(tmp_path):
+    """The reference's training entry point end to end on its own on-disk format: ControllerDataModule over episode_*.h5 ->
+    DiffusionControllerTrainer.train (one epoch: shuffled batches, device step, validation, best_model / epoch_1 checkpoints)."""
+    import os, shutil
+    from vlatouch import synth
+    from residual_controller.bridge_controller import DiffusionController
+    from residual_controller.bridge_train import DiffusionControllerTrainer
+    from residual_controller.controller_dataset import ControllerDataModule
+    d = tmp_path / "data"
+    d.mkdir()
+    for f in ("episode_1.h5", "episode_2.h5"):
+        shutil.copy(os.path.join(cases.GOLDEN, "episodes_h5", f), d)
+    np.random.seed(1)
+    torch.manual_seed(1)
+    dm = ControllerDataModule(str(d), batch_size=8, num_workers=0, context_frames=2, horizon=16, use_images=True)
+    ctrl = synth.build_controller(DiffusionController, "fp32", device="cuda:0")
+    tr = DiffusionControllerTrainer(ctrl, dm, learning_rate=1e-4, checkpoint_dir=str(tmp_path / "ck"), device="cuda:0")
+    best = tr.train(dm, num_epochs=1, save_interval=1, eval_interval=1, log_interval=1)
+    assert np.isfinite(best)
+    steps = [h for h in tr.history if "step" in h]
+    assert len(steps) == len(dm.train_dataset) // 8 and all(np.isfinite(h["loss"]) for h in steps)
+    for name in ("best_model", "epoch_1"):
+        assert sorted(os.listdir(tmp_path / "ck" / name)) == ["bridge_model.pt", "controller.pt"]
+    ck = torch.load(tmp_path / "ck" / "epoch_1" / "controller.pt", weights_only=False)
+    assert set(ck["stats"].keys()) >= {"action_mins", "vla_maxs"}
+
+
+def test_ragged_batch_is_padded_with_zero_weight_samples():
+    """B = 3 (a validation loader's last batch): same losses and gradients as the 3 samples repeated 4 times (B = 12, aligned)."""
+    from vlatouch.train import SITrainer
+    inp = train_inputs(1)
+    a = SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), device="cuda:0")
+    b = SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), device="cuda:0")
+    small = [inp[k][:3] for k in ("obs_in", "vla_n", "expert_n", "t", "z")]
+    rep = [torch.cat([x] * 4) for x in small]
+    la, ia = a.get_loss(*small)
+    lb, ib = b.get_loss(*rep)
+    assert abs(la - lb) < 2e-6 * abs(lb), (la, lb)
+    assert a.last_dcond.shape == (3, 256)
+    ga, gb = dict(a.net_grads()), dict(b.net_grads())
+    worst = max(float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)) for k in ga)
+    assert worst < 2e-5, worst
+
+
+def test_lstm_ragged_batch_is_padded_with_zero_weight_samples():
+    from vlatouch.train import LstmTrainer
+    from tools.make_golden_train_lstm import lstm_train_inputs
+    inp = lstm_train_inputs(1)
+    a, b = LstmTrainer(cases.lstm_mods(), device="cuda:0"), LstmTrainer(cases.lstm_mods(), device="cuda:0")
+    small = [inp[k][:3] for k in ("obs_in", "vla_n", "forces", "expert_n")]
+    la, pa = a.get_loss(*small)
+    lb, pb = b.get_loss(*[torch.cat([x] * 4) for x in small])
+    assert abs(la - lb) < 2e-6 * abs(lb) and pa.shape == (3, 16, 10) and float((pa - pb[:3]).abs().max()) < 1e-6
+    flat = lambda d: {f"{m}.{k}": v for m, sd in d.items() for k, v in sd.items()}
+    ga, gb = flat(a.modules_grads()), flat(b.modules_grads())
+    worst = max(float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)) for k in ga)
+    assert worst < 2e-5, worst

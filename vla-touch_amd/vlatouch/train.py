@@ -326,8 +326,9 @@ class TrainUNet:
         """sample [B,T,10], t [B], cond [B,256] (fp32, device) -> [B,T,10]; records the tape for `backward`."""
         p, dev = self.p, self.device
         B, T, D = sample.shape
-        if T % 4 or (B * T // 4) % 16:
-            raise ValueError("TrainUNet: T must be a multiple of 4 and B*T/4 a multiple of 16")
+        if T % 4 or B % 4:
+            raise ValueError("TrainUNet: T and B must be multiples of 4 (fp32 GEMM k alignment of the weight-gradient products, whose reduction "
+                             "runs over B or B*T/4 rows; SITrainer pads the batch with zero-weight samples)")
         pe = _empty((B, 256), dev)
         L.check(L.lib().vt_posemb(L.ptr(t), L.ptr(pe), B, 256, _sp(dev)), "vt_posemb")
         h1 = gemm(pe, p["t1.w"], p["t1.b"])
@@ -602,7 +603,13 @@ class SITrainer(_Optimizer):
         dev = self.device
         f = lambda a: a.to(dev, F32).contiguous()
         obs, x0, x1, t, z = f(obs), f(vla_n), f(expert_n), f(t), f(z) * self.d
-        B, T, D = x0.shape
+        Breal, T, D = x0.shape
+        B = Breal
+        while B % 4:                             # a ragged last batch: pad with samples that get no loss weight (their d loss / d out is 0,
+            B += 1                               # and every layer is per-sample, so they contribute nothing to any gradient)
+        if B != Breal:
+            grow = lambda a, fill=0.0: torch.cat([a, torch.full((B - Breal,) + tuple(a.shape[1:]), fill, dtype=F32, device=dev)])
+            obs, x0, x1, z, t = grow(obs), grow(x0), grow(x1), grow(z), grow(t, 0.5)
         cond = self.mlp.forward(obs) if self.mlp is not None else obs
         xt, tv, ts, tb = (torch.empty_like(x0) for _ in range(4))
         tc = _empty((B,), dev)
@@ -611,15 +618,15 @@ class SITrainer(_Optimizer):
         losses, dcond = {}, None
         for name, tgt in (("v_net", tv), ("s_net", ts), ("b_net", tb)):
             out = self.nets[name].forward(xt, tc, cond)
-            dout, loss = torch.empty_like(out), _empty((1,), dev)
-            L.check(L.lib().vt_si_loss(L.ptr(out), L.ptr(tgt), L.ptr(dout), L.ptr(loss), B, T * D, _sp(dev)), "vt_si_loss")
+            dout, loss = (torch.empty_like(out) if B == Breal else torch.zeros_like(out)), _empty((1,), dev)
+            L.check(L.lib().vt_si_loss(L.ptr(out), L.ptr(tgt), L.ptr(dout), L.ptr(loss), Breal, T * D, _sp(dev)), "vt_si_loss")
             losses[name[0] + "_loss"] = loss
             if backward:
                 dc = self.nets[name].backward(dout)
                 dcond = dc if dcond is None else add_(dcond, dc)
         if backward and self.mlp is not None:
             self.mlp.backward(dcond)
-        self.last_dcond = dcond
+        self.last_dcond = None if dcond is None else dcond[:Breal]
         if not sync:            # device tensors, no host read-back: what a captured (hipGraph) step returns
             return None, losses
         vals = {k: float(v.item()) for k, v in losses.items()}
@@ -767,7 +774,11 @@ class LstmTrainer(_Optimizer):
         dev, lib, sp, H = self.device, L.lib(), _sp(self.device), self.H
         f = lambda a: torch.as_tensor(a).to(dev, F32).contiguous()
         obs, vla, forces, expert = f(obs), f(vla_n), f(forces), f(expert_n)
-        B, T, D = vla.shape
+        Breal, T, D = vla.shape
+        B = (Breal + 3) // 4 * 4                 # ragged last batch: zero-weight padding samples (k alignment of the B-row weight-gradient products)
+        if B != Breal:
+            grow = lambda a: torch.cat([a, torch.zeros((B - Breal,) + tuple(a.shape[1:]), dtype=F32, device=dev)])
+            obs, vla, forces, expert = grow(obs), grow(vla), grow(forces), grow(expert)
         M = B * T
         cond = self.obs.forward(obs) if self.obs is not None else obs
         ef = self.force.forward(forces.reshape(M, -1))                           # [M, H/2]
@@ -795,8 +806,8 @@ class LstmTrainer(_Optimizer):
         if hm is not None:
             L.check(lib.vt_mul_(L.ptr(g1_), L.ptr(hm), g1_.numel(), sp), "vt_mul_")
         delta = ops.gemm(g1_, self.head["4.weight"], self.head["4.bias"])
-        pred, ddelta, loss = _empty((M, D), dev), _empty((M, D), dev), _empty((1,), dev)
-        L.check(lib.vt_mse_residual(L.ptr(vla), L.ptr(delta), L.ptr(expert), L.ptr(pred), L.ptr(ddelta), L.ptr(loss), M * D, sp), "vt_mse_residual")
+        pred, ddelta, loss = torch.zeros(M, D, dtype=F32, device=dev), torch.zeros(M, D, dtype=F32, device=dev), _empty((1,), dev)
+        L.check(lib.vt_mse_residual(L.ptr(vla), L.ptr(delta), L.ptr(expert), L.ptr(pred), L.ptr(ddelta), L.ptr(loss), Breal * T * D, sp), "vt_mse_residual")
         if backward:
             Dp = (D + 15) // 16 * 16                                              # GEMM k alignment: the D = 10 outputs padded with zeros
             ddp, w4p = torch.zeros(M, Dp, dtype=F32, device=dev), torch.zeros(Dp, H, dtype=F32, device=dev)
@@ -826,8 +837,8 @@ class LstmTrainer(_Optimizer):
             self.force.backward(def_)
             if self.obs is not None:
                 self.obs.backward(dcond)
-            self.last_dcond = dcond
-        return (float(loss.item()) if sync else loss), pred.reshape(B, T, D)
+            self.last_dcond = dcond[:Breal]
+        return (float(loss.item()) if sync else loss), pred.reshape(B, T, D)[:Breal]
 
     # ---- parameters in the reference's layout
     def _all(self):
