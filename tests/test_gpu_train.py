@@ -354,3 +354,30 @@ def test_lstm_ragged_batch_is_padded_with_zero_weight_samples():
     ga, gb = flat(a.modules_grads()), flat(b.modules_grads())
     worst = max(float((ga[k] - gb[k]).norm() / (gb[k].norm() + 1e-20)) for k in ga)
     assert worst < 2e-5, worst
+
+
+def test_training_step_at_bench_batch_is_the_mean_of_its_sub_batches():
+    """Full-size property (B = 128, the reference's default batch and tools/train_bench.py's): every loss is a batch mean, so the
+    losses and gradients of the 128-sample step equal the average over its eight 16-sample sub-batches (whose arithmetic g13 pins)."""
+    from vlatouch.train import SITrainer
+    dev = "cuda:0"
+    gen = torch.Generator().manual_seed(11)
+    B = 128
+    r = lambda *s: torch.randn(*s, generator=gen)
+    obs, x0, x1, t, z = r(B, 781), r(B, 16, 10).clamp(-1, 1), r(B, 16, 10).clamp(-1, 1), torch.rand(B, generator=gen), r(B, 16, 10)
+    big = SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), device=dev)
+    lb, ib = big.get_loss(obs, x0, x1, t, z)
+    gb = dict(big.net_grads())
+    gb.update({"state_encoder." + k: v for k, v in big.mlp.grads().items()})
+    small = SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), device=dev)
+    acc, lsum = None, 0.0
+    for i in range(0, B, 16):
+        sl = slice(i, i + 16)
+        l, _ = small.get_loss(obs[sl], x0[sl], x1[sl], t[sl], z[sl])
+        lsum += l
+        g = dict(small.net_grads())
+        g.update({"state_encoder." + k: v for k, v in small.mlp.grads().items()})
+        acc = {k: v.double() for k, v in g.items()} if acc is None else {k: acc[k] + g[k].double() for k in g}
+    assert abs(lb - lsum / 8) < 2e-6 * abs(lb), (lb, lsum / 8)
+    worst = max(float((gb[k].double() - acc[k] / 8).norm() / (acc[k].norm() / 8 + 1e-30)) for k in gb)
+    assert worst < 5e-5, worst
