@@ -377,6 +377,7 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.a_dtype == VT_F32 && p.w_dtype == VT_BF16) {
     return p.c_dtype == VT_BF16 ? launch_cfg<float, bf16_t, bf16_t>(p, s) : launch_cfg<float, bf16_t, float>(p, s);
   }
+  if (vt_gemm_f32r_eligible(p)) return vt_gemm_f32r_launch(p, s);      // exact fp32, few blocks per CU: LDS-DMA ring (vt_gemm_f32r.hip)
   if (p.a_dtype == VT_F32 && p.w_dtype == VT_F32 && p.c_dtype == VT_F32) return launch_cfg<float, float, float>(p, s);
   if (p.a_dtype == VT_F32 && p.w_dtype == VT_F32X3 && p.c_dtype == VT_F32) return launch_cfg<float, x3_t, float>(p, s);
   return VT_ERR_UNSUPPORTED;

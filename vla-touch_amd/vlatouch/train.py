@@ -102,13 +102,14 @@ def gelu(x: torch.Tensor, dy: Optional[torch.Tensor] = None) -> torch.Tensor:
 def _splits(M: int, N: int, K: int) -> int:
     """Split-K factor for the fp32 64x64-tile GEMM: the backward pass is full of products with few output tiles and a long reduction
     (weight gradients: [Cout, k*Cin] outputs reduced over B*T rows; the T=4 levels: 512-row activations against k*Cin = 2560..5120) —
-    one 4-wave block per tile leaves most of the 256 CUs idle and nothing to hide the staging latency behind.  Aim at >= 512 blocks of
-    64x64 (two per CU; tools/gemm_bench_f32.py: the best factor on every shape of the step, more splits only add slab traffic)."""
+    one 4-wave block per tile leaves most of the 256 CUs idle.  Aim at >= 512 blocks of 64x64 (two per CU, what the LDS ring of
+    csrc/vt_gemm_f32r.hip is sized for) while a slice keeps >= 256 of the reduction (tools/gemm_bench_f32.py: within 5 % of the best
+    factor on every shape of the step; more splits only add slab traffic)."""
     if N % 4 or os.environ.get("VLATOUCH_TRAIN_SPLITK", "1") == "0":
         return 1
     blocks = ((M + 63) // 64) * ((N + 63) // 64)
     s = 1
-    while s < 16 and blocks * s < 512 and K // (2 * s) >= 128:
+    while s < 16 and blocks * s < 512 and K // (2 * s) >= 256:
         s *= 2
     return s
 
