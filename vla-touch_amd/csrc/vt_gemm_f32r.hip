@@ -29,7 +29,21 @@ __device__ float vt_zero_page[32];                 // 128 B of zeros: the source
 
 // RING = 4: 64 KiB, two blocks per CU.  (A 6-deep ring at one block per CU was measured on every shape of tools/gemm_bench_f32.py: never
 // faster — a lone block is not waiting for data but for its own barrier / fragment-read / MFMA sequence, which a second block overlaps.)
-template <int RING>
+// X3: split-bf16 arithmetic on the same fp32 tiles (vt_gemm.hip: a b ~= a_hi b_hi + a_lo b_hi + a_hi b_lo on the bf16 MFMA): the 8 floats of a
+// fragment are exactly the 8 consecutive k of a v_mfma_f32_16x16x32_bf16 operand, so the split happens in registers after the fragment
+// read (v_cvt_pk_bf16_f32 per pair) and a 32-deep k-tile costs 3 MFMAs per accumulator instead of 8.
+__device__ __forceinline__ void split8(const Frag<float>& f, Frag<bf16_t>& hi, Frag<bf16_t>& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = pk_bf16(f.v[2 * j], f.v[2 * j + 1]);
+    l[j] = pk_bf16(f.v[2 * j] - __uint_as_float(h[j] << 16), f.v[2 * j + 1] - __uint_as_float(h[j] & 0xffff0000u));
+  }
+  hi.v = __builtin_bit_cast(short8_t, make_uint4(h[0], h[1], h[2], h[3]));
+  lo.v = __builtin_bit_cast(short8_t, make_uint4(l[0], l[1], l[2], l[3]));
+}
+
+template <int RING, bool X3>
 __global__ __launch_bounds__(256, 2) void gemm_f32r_kernel(const VtGemmParams p) {
   __shared__ __attribute__((aligned(16))) char smem[RING * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -114,13 +128,29 @@ __global__ __launch_bounds__(256, 2) void gemm_f32r_kernel(const VtGemmParams p)
 #pragma unroll
     for (int n = 0; n < 2; ++n) lds_frag(f.w[n], Bs, wn * 32 + n * 16 + l15, g);
   };
-  auto mfmas = [&](const Frags& f) {      // the four accumulators advance together, one 4-deep slice at a time (each sums its slices in order)
+  auto mfmas = [&](const Frags& f) {
+    if constexpr (X3) {                   // small terms first, as gemm_kernel's split mode orders them
+      Frag<bf16_t> ah[2], al[2], wh[2], wl[2];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+      for (int j = 0; j < 2; ++j) split8(f.a[j], ah[j], al[j]);
+#pragma unroll
+      for (int n = 0; n < 2; ++n) split8(f.w[n], wh[n], wl[n]);
 #pragma unroll
       for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[n].v[e], f.a[j].v[e], acc[n][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) { mma16(acc[n][j], wl[n], ah[j]); mma16(acc[n][j], wh[n], al[j]); }
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma16(acc[n][j], wh[n], ah[j]);
+    } else {                              // the four accumulators advance together, one 4-deep slice at a time (each sums its slices in order)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.w[n].v[e], f.a[j].v[e], acc[n][j], 0, 0, 0);
+    }
   };
   // Software pipeline: the MFMAs of k-tile i only read registers, so they are issued LAST in iteration i and execute while the wave, in
   // iteration i+1, waits for tile i+2, passes the barrier, re-stages a slot and reads the next fragments.  Tile t lives in slot t % RING.
@@ -193,7 +223,8 @@ static int f32r_mode() { static const int m = [] { const char* e = getenv("VLATO
 
 bool vt_gemm_f32r_eligible(const VtGemmParams& p) {
   if (f32r_mode() == 0) return false;
-  if (p.a_dtype != VT_F32 || p.w_dtype != VT_F32 || p.c_dtype != VT_F32) return false;
+  if (p.a_dtype != VT_F32 || (p.w_dtype != VT_F32 && p.w_dtype != VT_F32X3) || p.c_dtype != VT_F32) return false;
+  if (p.w_dtype == VT_F32X3 && (f32r_mode() == 1 || p.K % 64)) return false;     // VLATOUCH_F32_RING=1: ring for exact fp32 only (A/B); K % 64: gemm_kernel's slices
   if (p.act != VT_ACT_NONE || p.colscale || p.residual || p.hn_w0 || p.hn_w1 || p.cmap) return false;
   if (p.K % BK || p.K < 2 * BK || p.lda % 4 || p.ldw % 4) return false;
   if (p.taps && (p.cin % BK || p.K != p.taps * p.cin)) return false;
@@ -206,6 +237,7 @@ bool vt_gemm_f32r_eligible(const VtGemmParams& p) {
 int vt_gemm_f32r_launch(const VtGemmParams& p, hipStream_t s) {
   VtProfScope prof(5, p, s);
   dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, p.groups * p.splitk);
-  hipLaunchKernelGGL(gemm_f32r_kernel<4>, grid, dim3(256), 0, s, p);
+  if (p.w_dtype == VT_F32X3) hipLaunchKernelGGL((gemm_f32r_kernel<4, true>), grid, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((gemm_f32r_kernel<4, false>), grid, dim3(256), 0, s, p);
   return vt_check_launch();
 }
