@@ -253,3 +253,40 @@ def test_attention_head_dim_96(dev, mode, Nq, Nk):
     ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, Nq, H * 96)
     assert rel_err(out.float(), ref) < {"f32": 3e-5, "bf16": 1.5e-2, "f16": 2e-3}[mode]
     assert float(out.float().reshape(B, Nq, H, 96)[..., 72:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,N,K,splitk", [(70, 100, 64, 1), (33, 64, 96, 1), (200, 260, 1056, 1), (512, 512, 2560, 3), (64, 1280, 2048, 8), (257, 36, 160, 2)])
+def test_fp32_ring_gemm_edges(dev, M, N, K, splitk):
+    """vt_gemm_f32r.hip (bias-only exact-fp32 products with few blocks per CU): ragged M / N (clamped rows, scalar stores when N % 4 != 0),
+    fewer k-tiles than ring slots, uneven split-K slices."""
+    from vlatouch import ops
+    a, w, bias = rnd((M, K), 1, dev), rnd((N, K), 2, dev, torch.float32, K ** -0.5), rnd((N,), 3, dev)
+    ref = a.double().cpu() @ w.double().cpu().t()
+    if splitk == 1:
+        out = ops.gemm(a, w, bias)
+        assert rel_err(out, ref + bias.double().cpu()) < 2e-6
+        assert rel_err(ops.gemm(a, w), ref) < 2e-6
+    else:
+        slabs = ops.gemm(a, w, splitk=splitk)
+        assert slabs.shape == (splitk, M, N) and rel_err(slabs.sum(0), ref) < 2e-6
+
+
+@pytest.mark.parametrize("cfg", [dict(cin=64, cout=96, k=5, T=16, stride=1, splitk=1), dict(cin=64, cout=96, k=3, T=16, stride=2, splitk=1),
+                                 dict(cin=512, cout=256, k=5, T=4, stride=1, splitk=4), dict(cin=32, cout=40, k=5, T=8, stride=1, splitk=1)])
+def test_fp32_ring_conv_edges(dev, cfg):
+    """The ring kernel's conv mode: taps that fall in the padding read the zero page; strided outputs; split-K over (tap, channel) tiles."""
+    from vlatouch import ops
+    B, cin, cout, k, T, stride, sk = 9, cfg["cin"], cfg["cout"], cfg["k"], cfg["T"], cfg["stride"], cfg["splitk"]
+    x = rnd((B, T, cin), 1, dev)
+    w = rnd((cout, cin, k), 2, dev, torch.float32, (cin * k) ** -0.5)
+    b = rnd((cout,), 3, dev)
+    wp = _pack_conv(w, cin).to(dev)
+    pad = k // 2
+    tout = (T + 2 * pad - k) // stride + 1
+    ref = F.conv1d(x.double().cpu().transpose(1, 2), w.double().cpu(), None, stride=stride, padding=pad).transpose(1, 2)
+    if sk == 1:
+        out = ops.conv1d_cl(x, wp, b, taps=k, cin=cin, tout=tout, stride=stride, off0=-pad)
+        assert rel_err(out, ref + b.double().cpu()) < 2e-6
+    else:
+        slabs = ops.conv1d_cl(x, wp, None, taps=k, cin=cin, tout=tout, stride=stride, off0=-pad, splitk=sk)
+        assert rel_err(slabs.sum(0), ref) < 2e-6
