@@ -14,6 +14,8 @@ oracle's stepper (oracle/dpm_solver.py) are both held to these.
 """
 import math
 
+import pytest
+
 import numpy as np
 import torch
 
@@ -115,3 +117,26 @@ def test_epsilon_prediction_is_the_same_update():
     ac = _alphas_cumprod()
     np.testing.assert_allclose(coef[:, 3], np.sqrt(ac[ts]), atol=2e-6)
     np.testing.assert_allclose(coef[:, 4], np.sqrt(1 - ac[ts]), atol=2e-6)
+
+
+def test_schedule_against_diffusers_when_installed():
+    """Where diffusers IS importable (a maintainer's machine, not this image): the product's folded update x <- a x + b0 x0_k + b1 x0_{k-1}
+    must reproduce `DPMSolverMultistepScheduler.step` on random tensors, with the scheduler constructed as models/rdt_runner.py:69-76 does."""
+    diffusers = pytest.importorskip("diffusers")
+    import torch
+    from vlatouch import dpm
+    for n in (3, 5, 50):
+        sch = diffusers.DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_schedule="squaredcos_cap_v2", prediction_type="sample")
+        sch.set_timesteps(n)
+        ts, coef = dpm.schedule(1000, "squaredcos_cap_v2", n)
+        assert [int(t) for t in sch.timesteps] == [int(t) for t in ts]
+        g = torch.Generator().manual_seed(n)
+        x = torch.randn(2, 64, 128, generator=g, dtype=torch.float64)
+        mine, prev = x.clone(), None
+        for k, t in enumerate(sch.timesteps):
+            x0 = torch.randn(2, 64, 128, generator=g, dtype=torch.float64)
+            x = sch.step(x0, t, x).prev_sample
+            a, b0, b1 = (float(c) for c in coef[k][:3])
+            mine = a * mine + b0 * x0 + (b1 * prev if prev is not None else 0.0)
+            prev = x0
+            assert float((mine - x).abs().max()) < 5e-5 * max(1.0, float(x.abs().max())), (n, k)
