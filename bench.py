@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dino", default="base", choices=["small", "base"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm", "marker"],
+    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm", "marker", "train", "train_lstm"],
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
@@ -82,6 +82,13 @@ def synth_inputs(B, T, res, seed, device):
 
 def main():
     args = parse()
+    if args.workload in ("train", "train_lstm"):     # the controller training step (one JSON line, tools/train_bench.py; 1 GPU)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import train_bench
+        B = args.batch if args.batch != 32 else 128                   # the reference's training default (bridge_train.py:698)
+        fn = train_bench.bench_si if args.workload == "train" else train_bench.bench_lstm
+        print(json.dumps(fn(B, args.steps)))
+        return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
