@@ -86,5 +86,35 @@ def main():
     print("wrote g13_train", len(out), "arrays")
 
 
+def time_reference(batch: int = 128, iters: int = 3):
+    """Wall time of the REFERENCE's own training step on this container's CPU (torch autograd + AdamW + EMA), for DESIGN §6."""
+    import time
+    ref_import.setup()
+    ref_import.no_cuda()
+    from bridge.bridge_model import StochasticInterpolants  # reference
+    si = StochasticInterpolants()
+    si.load_model(dict(cases.MODEL_ARGS), "cpu")
+    si.net.load_state_dict(cases.si_net_sd(""))
+    si.net.train()
+    enc = torch.nn.Sequential(torch.nn.Linear(781, 256), torch.nn.GELU(), torch.nn.Linear(256, 256), torch.nn.GELU(), torch.nn.Linear(256, 256))
+    opt = torch.optim.AdamW(list(si.net.parameters()) + list(enc.parameters()), lr=1e-4, weight_decay=1e-6)
+    g = torch.Generator().manual_seed(0)
+    obs, x0, x1 = torch.randn(batch, 781, generator=g), torch.randn(batch, T, 10, generator=g), torch.randn(batch, T, 10, generator=g)
+    ts = []
+    for i in range(iters + 1):
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        loss, _ = si.get_loss({"obs_cond": enc(obs), "expert_act": x1, "vla_act": x0}, "cpu")
+        loss.backward()
+        opt.step()
+        si.ema.update()
+        ts.append(time.perf_counter() - t0)
+    print(f"reference training step on CPU ({torch.get_num_threads()} threads), B={batch}: {min(ts[1:]) * 1e3:.0f} ms/step "
+          f"= {batch / min(ts[1:]):.0f} samples/s")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "--time":
+        time_reference(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
+    else:
+        main()

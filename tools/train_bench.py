@@ -8,7 +8,7 @@ step of either head, inputs resident on the device; `roofline` = the dominant ke
 GEMMs (`gemm_f32r_kernel`, `gemm_kernel<float,float,float,...>`): algorithmic 2·M·N·K flops of its launches in ONE eager step ÷ the HIP-event time of those
 launches (vt_prof class 5), against the fp32 matrix peak (256 CUs x 256 flop/clk x 2.4 GHz = 157.3 TFLOP/s, MI355X_MICROARCH.md).
 No `cpu_baseline`: the CPU side of this row is the reference's own torch autograd step, which cannot travel to the GPU box; its time in the
-build container is recorded by tools/make_golden_train.py's run.
+build container (`python tools/make_golden_train.py --time 128`: 882 ms/step on 8 threads) is recorded in DESIGN §6.
 """
 import argparse
 import ctypes as C
