@@ -135,3 +135,43 @@ def test_convert_raw_episode_folder_and_labelled_writer(tmp_path):
     assert np.array_equal(e["vla_action"], vla) and np.array_equal(e["camera2_resized"], cam[::-1]) and e["gelsight_force/forces"].shape == (N, 3)
     with pytest.raises(ValueError):
         convert.write_labelled_episode(out, lab, vla[:-1], cam, cam)
+
+
+# ---- property tests (hypothesis): the codec and the container on arbitrary inputs
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.binary(min_size=0, max_size=4096), st.integers(1, 40), st.integers(0, 3))
+def test_lzf_round_trip_property(chunk, repeat, mode):
+    """decompress(compress(x)) == x for any byte string (repetitive, mixed or empty), on both decoders; a None from the encoder means
+    'stored raw' (not compressible into fewer bytes), exactly liblzf's contract."""
+    raw = chunk * repeat if mode < 2 else chunk + bytes(len(chunk)) * repeat + chunk[::-1]
+    if mode == 3:
+        raw = raw[: len(raw) // 2]
+    c = H.lzf_compress(raw)
+    if c is None:
+        return
+    assert len(c) < max(len(raw), 1)
+    assert H.lzf_decompress(c, len(raw)) == raw
+    assert H.lzf_decompress_py(c, len(raw)) == raw
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.lists(st.tuples(st.sampled_from(["u1", "i2", "i4", "f4", "f8", "i8"]), st.lists(st.integers(1, 9), min_size=1, max_size=4), st.integers(0, 2 ** 31)),
+                min_size=1, max_size=5))
+def test_writer_reader_round_trip_property(tmp_path_factory, specs):
+    """write_file -> File for arbitrary dtypes / ranks / shapes (compressible and incompressible contents, nested group)."""
+    tree = {}
+    for i, (dt, shape, seed) in enumerate(specs):
+        rng = np.random.default_rng(seed)
+        a = rng.integers(0, 5 if seed % 2 else 250, size=shape).astype(dt) if dt[0] in "ui" else rng.standard_normal(shape).astype(dt)
+        tree[f"d{i}" if i % 2 == 0 else f"grp/d{i}"] = a
+    p = str(tmp_path_factory.mktemp("h5p") / "t.h5")
+    H.write_file(p, tree)
+    with H.File(p) as f:
+        for k, v in tree.items():
+            got = f[k][...]
+            assert got.dtype == v.dtype and got.shape == v.shape and np.array_equal(got, v), k
+            if v.ndim >= 1 and v.shape[0] > 1:
+                assert np.array_equal(f[k][1:], v[1:])
