@@ -20,13 +20,13 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
                                                TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok) {   // CMAP here is 0 or 1
   float o[4] = {x.x + b4.x, x.y + b4.y, x.z + b4.z, x.w + b4.w};
   if (hw) {   // per-head RMSNorm over the row's 64 columns = the 16 lanes sharing lane>>4 (wave-uniform branch; all lanes shuffle)
-    float s = o[0] + o[1] + o[2] + o[3];
     float q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
-    s = row16_sum(s);
     q = row16_sum(q);
     float var;
-    if (p.hn_mode == 2) { const float mean = s * (1.f / 64.f); var = (q - 64.f * mean * mean) * (1.f / 63.f); }
-    else var = q * (1.f / 64.f);
+    if (p.hn_mode == 2) {      // the row sum is only needed by the variance form (wave-uniform branch)
+      const float mean = row16_sum(o[0] + o[1] + o[2] + o[3]) * (1.f / 64.f);
+      var = (q - 64.f * mean * mean) * (1.f / 63.f);
+    } else var = q * (1.f / 64.f);
     const float rstd = rsqrtf(var + p.hn_eps);
     o[0] *= rstd * hw4.x; o[1] *= rstd * hw4.y; o[2] *= rstd * hw4.z; o[3] *= rstd * hw4.w;
   }
