@@ -165,6 +165,25 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   // GEMMs 330 -> 490) except when the grid cannot fill the slots, where the two-stage kernel hides latency inside the block;
   // 128-row tiles when they fill the slots, else 64-row tiles.  GEMMs with several rounds of 256-square tiles go to the
   // ping-pong kernel of vt_gemm_pp.hip (half the L2 -> LDS bytes per flop).
+  // A ragged last row block that costs a whole extra round of 256-square tiles (DINOv2-base: 64 images x 257 tokens = 64 x 256 + 64
+  // rows; fc1's 65 x 12 = 780 tiles are 3.05 rounds of the 256 CUs): the full row blocks go to the ping-pong kernel, the <= 64 remaining
+  // rows to a second small launch (rows are independent: an exact row split).  VLATOUCH_GEMM_ROWSPLIT=0 for A/B.
+  if (g_vt_force_bm == 0 && p.cmap == 0 && p.groups == 1 && p.M % 256 != 0 && p.M % 256 <= 64 && vt_gemm_pp_eligible(p)) {
+    static const bool on = [] { const char* e = getenv("VLATOUCH_GEMM_ROWSPLIT"); return !e || atoi(e) != 0; }();
+    const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
+    VtGemmParams a = p;
+    a.M = (int)((tm - 1) * 256);
+    if (on && tm > 1 && (tm * tn + 255) / 256 > ((tm - 1) * tn + 255) / 256 && vt_gemm_pp_eligible(a)) {
+      VtGemmParams b = p;
+      const size_t ea = p.a_dtype == VT_F32 ? 4 : 2, ec = p.c_dtype == VT_F32 ? 4 : 2;
+      b.M = p.M - a.M;
+      b.A = (const char*)p.A + (size_t)a.M * p.lda * ea;
+      b.C = (char*)p.C + (size_t)a.M * p.ldc * ec;
+      if (p.residual) b.residual = (const char*)p.residual + (size_t)a.M * p.ldr * ec;
+      const int rc = vt_gemm_pp_launch(a, s);
+      return rc != VT_OK ? rc : vt_gemm_launch(b, s);
+    }
+  }
   if (g_vt_force_bm == 256 || (g_vt_force_bm == 0 && vt_gemm_pp_eligible(p))) return vt_gemm_pp_launch(p, s);
   if ((g_vt_force_bm == 160 || g_vt_force_bm == 0) && vt_gemm_ppk_eligible(p)) return vt_gemm_ppk_launch(p, s);
   int bm = tiles128 < 1024 ? 64 : 128;
