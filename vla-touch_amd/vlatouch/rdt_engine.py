@@ -118,7 +118,9 @@ class RdtEngine:
         t = torch.as_tensor(t).to(torch.float32).reshape(-1)
         scalar = t.numel() == 1
         tdev = None if scalar else t.to(dev).contiguous()
-        mask = None if lang_mask is None else lang_mask.to(dev).to(torch.uint8).contiguous()
+        mask = None if lang_mask is None else lang_mask.to(dev).contiguous()
+        if mask is not None:
+            mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
         out = torch.empty(B, self.horizon, self.action_dim, dtype=dt, device=dev)
         L.check(L.lib().vt_rdt_forward(self._h, L.ptr(x), L.ptr(freq), L.ptr(tdev), float(t[0]) if scalar else 0.0, int(scalar), L.ptr(lang_c),
                                        L.ptr(img_c), L.ptr(mask), L.ptr(out), B, Llang, L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)),
@@ -160,7 +162,8 @@ class RdtEngine:
         action_mask = action_mask.to(dev, dt).contiguous()
         ctrl_freqs = ctrl_freqs.to(dev, torch.float32).contiguous()
         x_init = x_init.to(dev, torch.float32).contiguous()
-        mask = lang_attn_mask.to(dev).to(torch.uint8).contiguous()
+        mask = lang_attn_mask.to(dev).contiguous()
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)        # bool is one byte of 0 / 1: no cast kernel
         out = torch.empty(B, self.horizon, self.action_dim, dtype=torch.float32, device=dev)
         L.check(L.lib().vt_rdt_sample(self._h, L.ptr(lang_tokens), L.ptr(mask), L.ptr(img_tokens), L.ptr(state_tokens), L.ptr(action_mask),
                                       L.ptr(ctrl_freqs), L.ptr(x_init), len(ts), ts_c, coef_c, int(prediction_type == "sample"), int(adapted), L.ptr(out), B, Llang,
