@@ -140,6 +140,7 @@ def main():
         if world > 1:
             from vlatouch.dist import broadcast_tensors
             broadcast_tensors(eng._weights, src=0)
+            eng.repack()                                                 # the fragment-packed copies follow the received weights
         g = torch.Generator(device=dev).manual_seed(4321 + rank)
         rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32).to(rdt_dtype)
         amask = torch.zeros(B, 1, 128, device=dev, dtype=rdt_dtype)
@@ -439,7 +440,12 @@ def main():
             rdt_diff = float((gpu_chunk[0].float().cpu() - ref_chunk[0]).abs().max())
             rdt_scale = float(ref_chunk.abs().max())
             sample += f"; RDT-1B: 1 oracle predict_action on 1 episode ({args.rdt_steps} steps, fp32)"
-        res["cpu_baseline"] = {"value": round(1.0 / (t_pi + t_rdt), 3), "unit": "chunks/s", "cores": cores, "kind": "port", "sample": sample,
+        try:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            cpu_model = "unknown"
+        res["cpu_baseline"] = {"value": round(1.0 / (t_pi + t_rdt), 3), "unit": "chunks/s", "cores": cores, "cpu_model": cpu_model,
+                               "host_logical_cpus": os.cpu_count(), "kind": "port", "sample": sample,
                                "pi_s_per_chunk": round(t_pi, 4), "rdt_s_per_chunk": round(t_rdt, 3),
                                "max_abs_diff_vs_gpu_pi": float((got - ref).abs().max())}
         if args.workload == "full":

@@ -46,6 +46,14 @@ int vt_prof_collect(double* total_ms, double* flops, double* bytes, long* launch
  * Replaces torch nn.Linear / nn.Conv1d / nn.ConvTranspose1d calls of
  * bridge/networks/conditional_unet_1D.py:25,34,49,83, bridge_controller.py:42-48, HF Dinov2 linears. */
 int vt_gemm(const void* params, vt_stream_t stream);
+/* Frozen 16-bit weights W [N][K] (row stride ldw) -> a second copy in MFMA fragment order [N/32][K/16][64 lanes][8] (N % 32 == 0,
+ * K % 16 == 0; same byte count): VtGemmParams.Wp of the weights-in-registers GEMM tile (csrc/vt_gemm_pw.hip).  Replaces nothing in
+ * the reference (torch.nn.Linear keeps one layout, models/rdt/blocks.py:144-183); it is the load-time packing of this engine. */
+int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t stream);
+/* A/B tuning knobs of the GEMM dispatcher (tools/, tests): knob 1 = ring depth of the weights-in-registers tile (0 default, 4, 8);
+ * knob 2 = that tile on (1) / off (0). */
+int vt_tune(int knob, int value);
+
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
  * Replaces F.scaled_dot_product_attention (models/rdt/blocks.py:116-123) and HF Dinov2SelfAttention. */
 int vt_attention(const void* params, vt_stream_t stream);
@@ -96,6 +104,12 @@ int vt_unet_forward(vt_unet_t h, const float* x, const float* t_dev, float t_hos
 int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max,
                  int gamma_type, int epsilon_type, int sde_type, float* traj, int B, int T, void* workspace,
                  vt_stream_t stream);
+/* The same with the two remaining arguments of sde_vs / sde_bs (bridge_model.py:281, 334): backward != 0 = direction='backward' (nets and
+ * schedules evaluated at 1 - t, x <- x - (b - w eps s) dt, :356-361, :379-382; the epsilon inside b stays at t as :369 writes it),
+ * score_weight = w (:376).  vt_si_sample == vt_si_sample_ex(..., 0, 1.0f, ...). */
+int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max,
+                    int gamma_type, int epsilon_type, int sde_type, int backward, float score_weight, float* traj,
+                    int B, int T, void* workspace, vt_stream_t stream);
 /* In-place per-head RMSNorm over 64-wide head slices (timm Attention q_norm/k_norm, models/rdt/blocks.py:150-156):
  * x[token*tok_stride + head*64 + 0..63], mode as vt_rownorm (1 or 2). */
 int vt_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode,
@@ -179,6 +193,10 @@ int vt_rdt_create(const vt_rdt_desc* desc, const void* const* weights, int n_wei
 void vt_rdt_destroy(vt_rdt_t h);
 int vt_rdt_num_weights(const vt_rdt_desc* desc);
 size_t vt_rdt_workspace_bytes(vt_rdt_t h, int B, int lang_len);
+/* Optional fragment-packed second copies of the Linears of the denoise loop (vt_pack_w32 layout; bf16, hidden % 512 == 0): the caller
+ * allocates vt_rdt_packed_bytes(h) bytes (0 = not applicable), vt_rdt_set_packed enqueues the packing kernels and keeps the pointers. */
+size_t vt_rdt_packed_bytes(vt_rdt_t h);
+int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream);
 /* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the
  * scalar t_host when t_is_scalar, lang_c [B][L][hidden] / img_c [B][img_len][hidden] adt (adapted, before position
  * embeddings), lang_mask [B][L] bytes (1 = valid) or NULL -> out [B][horizon][out_dim] adt. */
@@ -206,7 +224,9 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
  * binary_out [N][H][W] bytes (0/1; the reference's `processed_frame` / 255) or NULL.
  * mode 0: gelsight_version 'standard' (init_standard).  mode 1: `frames` is already a processed binary image [N][H][W] (non-zero =
  * marker), only the contour stage runs (detect_markers :154).  mode 2: 'HSR' (init_HSR :116-152: invert, equalizeHist, 5x5 blur,
- * threshold > 50, 3x3 open). */
+ * threshold > 50, 3x3 open).  mode | 0x100: BGR2GRAY with the 14-bit coefficient table of OpenCV <= 3.4.1 ((1868 B + 9617 G + 4899 R +
+ * 8192) >> 14) instead of the 15-bit set of OpenCV >= 3.4.2 / 4.x ((3735 B + 19235 G + 9798 R + 16384) >> 15, the default: what the
+ * reference's unpinned `opencv-python` resolves to). */
 size_t vt_marker_workspace_bytes(int N, int H, int W, int max_cand);
 int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H, int W, double min_area, double max_area,
                      int max_cand, int* markers, int* counts, int max_markers, uint8_t* binary_out, void* workspace,

@@ -64,8 +64,10 @@ def gamma_inv(t: torch.Tensor, kind: str) -> torch.Tensor:
 
 def sde_bs(b_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torch.Tensor,
            noise: torch.Tensor, diffuse_step: int = 10, beta_max: float = 0.03,
-           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t") -> Tuple[torch.Tensor, List[torch.Tensor]]:
-    """Forward drift-score SDE (bridge_model.py:281-332): x += (b + eps*s*gamma_inv)*dt + dt*sqrt(2 eps)*d*z."""
+           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t", score_weight: float = 1.0,
+           direction: str = "forward") -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Drift-score SDE (bridge_model.py:281-332): forward x += (b + w*eps*s*gamma_inv)*dt + dt*sqrt(2 eps)*d*z; backward (:297-301,
+    :320-323): nets / gamma_inv / eps at 1 - t, x -= (b - w*eps*s)*dt."""
     delta_t = float(1.0 / diffuse_step)
     n_steps = int(1.0 / delta_t)
     n = x_initial.shape[0]
@@ -73,19 +75,23 @@ def sde_bs(b_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torc
     for k in range(1, n_steps + 1):
         x = xs[-1]
         t = torch.clip(torch.full((n,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
-        b = b_net(x, t, cond)
-        s = s_net(x, t, cond) * gamma_inv(t, gamma_type)[:, None, None]
+        tn = t if direction == "forward" else 1.0 - t
+        b = b_net(x, tn, cond)
+        s = s_net(x, tn, cond) * gamma_inv(tn, gamma_type)[:, None, None]
         dW = beta_max * noise[k - 1]
-        noise_scale = delta_t * torch.sqrt(2 * epsilon(t[0], epsilon_type))
-        new_x = x + (b + 1.0 * epsilon(t[0], epsilon_type) * s) * delta_t
+        noise_scale = delta_t * torch.sqrt(2 * epsilon(tn[0], epsilon_type))
+        score_eps = score_weight * epsilon(tn[0], epsilon_type)
+        new_x = x + (b + score_eps * s) * delta_t if direction == "forward" else x - (b - score_eps * s) * delta_t
         xs.append(new_x + noise_scale * dW)
     return xs[-1], xs
 
 
 def sde_vs(v_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torch.Tensor,
            noise: torch.Tensor, diffuse_step: int = 10, beta_max: float = 0.03,
-           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t") -> Tuple[torch.Tensor, List[torch.Tensor]]:
-    """Forward velocity-score SDE, Euler–Maruyama (bridge_model.py:334-387).
+           gamma_type: str = "2^0.5*t(t-1)", epsilon_type: str = "1-t", score_weight: float = 1.0,
+           direction: str = "forward") -> Tuple[torch.Tensor, List[torch.Tensor]]:
+    """Velocity-score SDE, Euler–Maruyama (bridge_model.py:334-387); direction='backward' (:356-361, :379-382) evaluates nets and gamma
+    schedules at 1 - t and steps x -= (b - w*eps(1-t)*s)*dt — the epsilon inside b stays eps(t), as :369 writes it.
 
     `v_net(x, t, cond)` / `s_net(x, t, cond)`; `noise[k-1]` is the N(0,1) draw of step k (the
     reference multiplies it by d = beta_max, :372).  Operation order follows the reference so
@@ -97,17 +103,18 @@ def sde_vs(v_net: Callable, s_net: Callable, x_initial: torch.Tensor, cond: torc
     for k in range(1, n_steps + 1):
         x = xs[-1]
         t = torch.clip(torch.full((n,), k / n_steps).float(), T_MIN, 1.0 - T_MIN)
-        g, gd = gamma(t, gamma_type), gamma_der(t, gamma_type)
-        v = v_net(x, t, cond)
-        s = s_net(x, t, cond)
-        gi = gamma_inv(t, gamma_type)
+        tn = t if direction == "forward" else 1.0 - t
+        g, gd = gamma(tn, gamma_type), gamma_der(tn, gamma_type)
+        v = v_net(x, tn, cond)
+        s = s_net(x, tn, cond)
+        gi = gamma_inv(tn, gamma_type)
         s = s * gi[:, None, None]
         gdg = (gd * g)[:, None, None]
         b = v - gdg * s * epsilon(t[0], epsilon_type)
         dW = beta_max * noise[k - 1]
-        noise_scale = delta_t * torch.sqrt(2 * epsilon(t[0], epsilon_type))
-        score_eps = 1.0 * epsilon(t[0], epsilon_type)
-        new_x = x + (b + score_eps * s) * delta_t
+        noise_scale = delta_t * torch.sqrt(2 * epsilon(tn[0], epsilon_type))
+        score_eps = score_weight * epsilon(tn[0], epsilon_type)
+        new_x = x + (b + score_eps * s) * delta_t if direction == "forward" else x - (b - score_eps * s) * delta_t
         new_x = new_x + noise_scale * dW
         xs.append(new_x)
     return xs[-1], xs

@@ -8,7 +8,12 @@ Restates /root/reference/VLA/residual_controller/tactile/marker/marker_tracker.p
 
 The image primitives are OpenCV's (`cv2`, third party, absent from /root/reference and from this image, not version-pinned
 by the reference) — PARITY UNPINNED for those: they are restated here from OpenCV's published algorithms (4.x sources):
-  * cvtColor BGR2GRAY 8-bit: (B*1868 + G*9617 + R*4899 + 8192) >> 14
+  * cvtColor BGR2GRAY 8-bit, TWO coefficient sets (GRAY_COEFFS, `gray_mode`): "cv4" = OpenCV >= 3.4.2 and every 4.x
+    (modules/imgproc/src/color_rgb.simd.hpp, RGB2Gray<uchar>: BY15 = 3735, GY15 = 19235, RY15 = 9798, gray_shift = 15,
+    CV_DESCALE -> (B*3735 + G*19235 + R*9798 + 16384) >> 15) — the DEFAULT, since the reference's unpinned `opencv-python`
+    (octopi/requirements.txt:2) resolves to 4.x; "cv3" = OpenCV <= 3.4.1 (color.cpp, the 14-bit table B2Y = 1868, G2Y = 9617,
+    R2Y = 4899, yuv_shift = 14 -> (B*1868 + G*9617 + R*4899 + 8192) >> 14).  The two differ by one grey level on ~0.3 % of
+    random colour pixels (and never on grey ones, B = G = R); known-answer tests for both in tests/test_marker.py.
   * GaussianBlur 5x5, sigma 0, 8-bit: fixed kernel [1 4 6 4 1]/16 (small_gaussian_tab), fixed-point, round half up,
     BORDER_REFLECT_101
   * adaptiveThreshold GAUSSIAN_C: float GaussianBlur 11x11 (sigma = 0.3*((11-1)*0.5-1)+0.8 = 2.0), BORDER_REPLICATE, rounded
@@ -28,9 +33,14 @@ import numpy as np
 
 
 # ------------------------------------------------------------------ OpenCV primitives (restated)
-def bgr2gray(frame: np.ndarray) -> np.ndarray:
+GRAY_COEFFS = {"cv4": (3735, 19235, 9798, 15), "cv3": (1868, 9617, 4899, 14)}     # (B, G, R, shift)
+GRAY_MODE = "cv4"                                                                  # module default (see the header)
+
+
+def bgr2gray(frame: np.ndarray, gray_mode: str = None) -> np.ndarray:
+    cb, cg, cr, sh = GRAY_COEFFS[gray_mode or GRAY_MODE]
     f = frame.astype(np.int64)
-    return ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+    return ((f[..., 0] * cb + f[..., 1] * cg + f[..., 2] * cr + (1 << (sh - 1))) >> sh).astype(np.uint8)
 
 
 def _reflect101(a: np.ndarray, r: int) -> np.ndarray:
@@ -171,9 +181,9 @@ def contour_area(pts: np.ndarray) -> float:
 
 
 # ------------------------------------------------------------------ the reference's pipeline (marker_tracker.py)
-def preprocess_standard(frame: np.ndarray) -> np.ndarray:
+def preprocess_standard(frame: np.ndarray, gray_mode: str = None) -> np.ndarray:
     """init_standard :81-114."""
-    gray = bgr2gray(frame) if frame.ndim == 3 else frame
+    gray = bgr2gray(frame, gray_mode) if frame.ndim == 3 else frame
     return morph_open3(adaptive_threshold_gaussian_inv(gaussian_blur5_u8(gray), 11, 2))
 
 
@@ -194,9 +204,9 @@ def equalize_hist(gray: np.ndarray) -> np.ndarray:
     return lut[gray]
 
 
-def preprocess_hsr(frame: np.ndarray) -> np.ndarray:
+def preprocess_hsr(frame: np.ndarray, gray_mode: str = None) -> np.ndarray:
     """init_HSR :116-152: gray -> 255 - gray -> equalizeHist -> GaussianBlur 5x5 -> threshold(> 50) -> MORPH_OPEN 3x3."""
-    gray = bgr2gray(frame) if frame.ndim == 3 else frame
+    gray = bgr2gray(frame, gray_mode) if frame.ndim == 3 else frame
     eq = equalize_hist((255 - gray.astype(np.int32)).astype(np.uint8))
     return morph_open3(np.where(gaussian_blur5_u8(eq) > 50, 255, 0).astype(np.uint8))
 

@@ -52,6 +52,7 @@ def main():
     # ---- the one-time weight broadcast (bench.py's start-up path)
     n1 = broadcast_controller_weights(ctrl, src=0)
     n2 = broadcast_tensors(r.engine()._weights, src=0)
+    r.engine().repack()
     assert n1 > 0 and n2 > 0
 
     # ---- the step loop: no collective may be called

@@ -95,6 +95,24 @@ def test_other_schedules_and_bs_integrator(controllers, tag, sde, gt, et):
         si.sde_type, si.gamma_type, si.epsilon_type = old
 
 
+@pytest.mark.parametrize("tag,sde,sw,direction", [("vs_backward_w07", "vs", 0.7, "backward"), ("bs_backward_w13", "bs", 1.3, "backward"),
+                                                  ("vs_forward_w05", "vs", 0.5, "forward")])
+def test_backward_direction_and_score_weight(controllers, tag, sde, sw, direction):
+    """sde_vs / sde_bs of the mirror with direction='backward' and score_weight != 1 against the reference's own run (g2 variants)."""
+    g = G(f"g2_si_{tag}")
+    si = controllers["fp32"].diffusion_model
+    x0, cond, _ = cases.si_inputs(2, 16)
+    fn = si.sde_bs if sde == "bs" else si.sde_vs
+    xT, traj = fn(x_initial=x0, cond=cond, delta_t=float(1.0 / 8), score_weight=sw, direction=direction, noise=torch.from_numpy(g["z"]))
+    assert len(traj) == 9
+    scale = max(1.0, float(np.abs(g["traj"]).max()))       # the backward SDE blows up in its last step (|x| ~ 77): relative tolerance there
+    assert err(torch.stack(traj[:-1]), g["traj"][:-1]) < 1e-4, (tag, err(torch.stack(traj[:-1]), g["traj"][:-1]))
+    assert err(torch.stack(traj), g["traj"]) < 1e-4 * scale, (tag, err(torch.stack(traj), g["traj"]))
+    assert err(xT, g["traj"][-1]) < 1e-4 * scale
+    with pytest.raises(NotImplementedError):
+        si.sde_vs(x_initial=x0, cond=cond, delta_t=0.125, direction="sideways")
+
+
 def test_error_behaviour_matches_reference(controllers):
     from residual_controller.bridge.bridge_model import StochasticInterpolants
     from residual_controller.controller_dataset import normalize_actions

@@ -56,6 +56,14 @@ def test_oracle_primitives_known_answers():
     # BGR -> gray fixed point: pure colours (OpenCV documents Y = 0.299 R + 0.587 G + 0.114 B)
     px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255]]], dtype=np.uint8)
     assert M.bgr2gray(px).tolist() == [[29, 150, 76, 255]]
+    assert M.bgr2gray(px, "cv3").tolist() == [[29, 150, 76, 255]]
+    # the two published coefficient sets (15-bit, OpenCV >= 3.4.2 / 4.x — the default — and 14-bit, OpenCV <= 3.4.1), on pixels whose exact
+    # luma 0.299 R + 0.587 G + 0.114 B sits within 2e-3 of a half: 27.499, 128.502, 133.501, 103.499
+    edge = np.array([[[55, 0, 71], [63, 197, 19], [236, 122, 117], [111, 59, 188]]], dtype=np.uint8)
+    assert M.bgr2gray(edge, "cv4").tolist() == [[27, 129, 133, 103]] == M.bgr2gray(edge).tolist()
+    assert M.bgr2gray(edge, "cv3").tolist() == [[28, 128, 134, 104]]
+    g3 = np.repeat(np.arange(256, dtype=np.uint8)[None, :, None], 3, axis=2)            # grey pixels: both sets are exact
+    assert (M.bgr2gray(g3, "cv4") == g3[..., 0]).all() and (M.bgr2gray(g3, "cv3") == g3[..., 0]).all()
     # binomial blur of an impulse of 256 -> the [1 4 6 4 1]^2 / 256 kernel itself (x256/256 rounded), constant stays constant
     imp = np.zeros((9, 9), dtype=np.uint8); imp[4, 4] = 255
     b = M.gaussian_blur5_u8(imp)
@@ -170,6 +178,24 @@ def test_device_tracker_vs_oracle_random_blobs_and_edges(H, W):
         ref = M.preprocess_hsr(f)
         assert np.array_equal(tr2.preprocess_frame(f), ref)
         assert np.array_equal(np.asarray(tr2.detect_markers(tr2.preprocess_frame(f))).reshape(-1, 2), M.detect_markers(ref))
+
+
+@gpu
+@pytest.mark.parametrize("gray", ["cv4", "cv3"])
+def test_device_gray_coefficient_sets(gray):
+    """BGR2GRAY on the device with either OpenCV coefficient set == the oracle's, on colour noise (where the sets disagree on ~0.3 % of the
+    pixels) and on the four known-answer pixels; the binary image that follows (blur, adaptive threshold, open) likewise."""
+    from residual_controller.tactile.marker.marker_tracker import EnhancedMarkerTracker
+    rng = np.random.default_rng(5)
+    f = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    f[0, :4] = [[55, 0, 71], [63, 197, 19], [236, 122, 117], [111, 59, 188]]
+    assert (M.bgr2gray(f, "cv4") != M.bgr2gray(f, "cv3")).any()
+    tr = EnhancedMarkerTracker(7, 9, device="cuda", opencv_gray=gray)
+    assert np.array_equal(tr.preprocess_frame(f), M.preprocess_standard(f, gray))
+    tr.gelsight_version = "HSR"
+    assert np.array_equal(tr.preprocess_frame(f), M.preprocess_hsr(f, gray))
+    with pytest.raises(ValueError):
+        EnhancedMarkerTracker(7, 9, device="cuda", opencv_gray="cv2")
 
 
 @gpu

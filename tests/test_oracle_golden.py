@@ -62,6 +62,25 @@ def test_g2_other_schedules_and_bs_integrator(tag, sde, gt, et):
     close(torch.stack(traj), g["traj"], 5e-5, tag)
 
 
+DIRECTION_CASES = [("vs_backward_w07", "vs", 0.7, "backward"), ("bs_backward_w13", "bs", 1.3, "backward"), ("vs_forward_w05", "vs", 0.5, "forward")]
+
+
+@pytest.mark.parametrize("tag,sde,sw,direction", DIRECTION_CASES)
+def test_g2_backward_direction_and_score_weight(tag, sde, sw, direction):
+    """The reference's sde_vs / sde_bs with the two arguments sample() never varies (bridge_model.py:281, 334)."""
+    g = G(f"g2_si_{tag}")
+    sd = cases.si_net_sd("ema")
+    x0, cond, _ = cases.si_inputs(2, 16)
+    first = "b_net." if sde == "bs" else "v_net."
+    a = lambda x, t, c: ou.unet_forward(sd, first, x, t, c)
+    s = lambda x, t, c: ou.unet_forward(sd, "s_net.", x, t, c)
+    fn = oi.sde_bs if sde == "bs" else oi.sde_vs
+    _, traj = fn(a, s, x0, cond, torch.from_numpy(g["z"]), 8, 0.03, score_weight=sw, direction=direction)
+    # the backward SDE leaves the data range in its last step (gamma_inv(1 - t) -> 200 at t = 0.999: |x| reaches ~77): tolerance relative to the state
+    close(torch.stack(traj), g["traj"], 5e-5 * max(1.0, float(np.abs(g["traj"]).max())), tag)
+    close(torch.stack(traj[:-1]), g["traj"][:-1], 5e-5, tag + " (steps before the last)")
+
+
 def test_g3_dino_cls():
     g = G("g3_dino_cls")
     sd = cases.dino_sd("small")

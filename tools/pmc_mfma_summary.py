@@ -20,6 +20,11 @@ with open(sys.argv[1]) as f:
 SIMDS, XCDS = 1024, 8
 rows = sorted(((a[3], k, a) for k, a in agg.items() if a[1] > 0), reverse=True)
 print("# per kernel: dispatches, total ms, MfmaUtil % = MFMA_BUSY_CYCLES / (GUI_ACTIVE/8 x 1024 SIMDs), effective clock GHz = GUI_ACTIVE/8 / wall")
+print("# NOTE on `clk`: GRBM_GUI_ACTIVE counts from before the first wave starts to after the last one retires, the kernel-trace wall time")
+print("#      does not: for launches under ~100 us the quotient exceeds the chip's 2.4 GHz maximum and is NOT a clock (marked '~').  Only")
+print("#      the long kernels' figure (the ~2 ms fused K|V projection) is an effective clock; MfmaUtil is a ratio of two counters and is")
+print("#      unaffected.")
 for wall, k, a in rows[:14]:
     gui = a[2] / XCDS
-    print(f"{k[:78]:78s} n={a[0]:5d} {wall/1e6:9.2f} ms  MfmaUtil={100*a[1]/(gui*SIMDS):5.1f}%  clk={gui/wall:4.2f} GHz")
+    short = wall / max(a[0], 1) < 100e3        # average launch under 100 us: the clock column is not meaningful
+    print(f"{k[:78]:78s} n={a[0]:5d} {wall/1e6:9.2f} ms  MfmaUtil={100*a[1]/(gui*SIMDS):5.1f}%  clk={'~' if short else ' '}{gui/wall:4.2f} GHz")

@@ -33,4 +33,7 @@ struct VtGemmParams {
   // cmap 0 = plain row-major C; 1 = K part; 2 = Vt part (written transposed from the epilogue patch); 3 = fused K|V projection
   // (N = 2*D: columns [0, D) -> K part, columns [D, 2D) -> Vt part of head (n - D)/64).  cmap_T = ceil(M/64).
   int cmap, cmap_T;
+  // optional second copy of W in MFMA fragment order (vt_pack_w32: [N/32][K/16][64 lanes][8], N % 32 == 0, K % 16 == 0) for the
+  // weights-in-registers tile of vt_gemm_pw.hip; null = not available.  W itself stays valid (other tile shapes read it).
+  const void* Wp;
 };

@@ -168,7 +168,8 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
   // A ragged last row block that costs a whole extra round of 256-square tiles (DINOv2-base: 64 images x 257 tokens = 64 x 256 + 64
   // rows; fc1's 65 x 12 = 780 tiles are 3.05 rounds of the 256 CUs): the full row blocks go to the ping-pong kernel, the <= 64 remaining
   // rows to a second small launch (rows are independent: an exact row split).  VLATOUCH_GEMM_ROWSPLIT=0 for A/B.
-  if (g_vt_force_bm == 0 && p.cmap == 0 && p.groups == 1 && p.M % 256 != 0 && p.M % 256 <= 64 && vt_gemm_pp_eligible(p)) {
+  if (g_vt_force_bm == 0 && vt_gemm_pw_eligible(p)) return vt_gemm_pw_launch(p, s);     // frozen, fragment-packed weights: W never touches LDS
+  if (g_vt_force_bm == 0 && p.cmap == 0 && p.groups == 1 && !p.hn_w0 && !p.hn_w1 && p.M % 256 != 0 && p.M % 256 <= 64 && vt_gemm_pp_eligible(p)) {
     static const bool on = [] { const char* e = getenv("VLATOUCH_GEMM_ROWSPLIT"); return !e || atoi(e) != 0; }();
     const long tm = (p.M + 255) / 256, tn = (p.N + 255) / 256;
     VtGemmParams a = p;

@@ -1,0 +1,278 @@
+// vt_gemm_pw.hip — 160 x 128 x 64 tile with the WEIGHT operand streamed global -> VGPR, for 16-bit GEMMs with FROZEN, pre-packed weights
+// whose grid is one round (or a few whole rounds) of such tiles: the per-denoise-step Linears of RDT (M = batch x 67 = 2144 rows,
+// N = 2048 or 6144, K = 2048; models/rdt/blocks.py:144-183 in the reference).
+//
+// Why: gemm_ppk_kernel (vt_gemm_ppk.hip) passes BOTH operands through LDS; per k-tile the CU's one LDS port takes 36 KiB of LDS-DMA
+// writes and 72 KiB of fragment reads that do not overlap (tools/ubench/fill3.hip), against ~650 clk of MFMA.  The weights never change
+// after load, so they are re-packed ONCE (vt_pack_w32) into MFMA fragment order
+//     Wp[n/32][k/16][lane = (k%16)/8 * 32 + n%32][k%8]        (a wave's fragment of a 32 x 16 block = one contiguous KiB)
+// and each wave streams the fragments of its OWN 32 output columns straight into registers with full-line global_load_dwordx4
+// (no LDS write, no LDS read, no duplicate fetch: every byte of W enters the CU once).  Only the activation tile goes through LDS:
+//   * 4 waves, one per SIMD (up to 512 VGPRs: accumulators 80, NB weight buffers x 16, two fragment sets x 20); wave w owns the
+//     160 x 32 sub-tile at columns 32 w: 5 accumulators of v_mfma_f32_32x32x16 (D[n][m] = W-fragment x A-fragment, so a lane ends with
+//     4 consecutive n of one row m);
+//   * A k-tiles (160 rows x 128 B = 20 pieces of 1 KiB, XOR-swizzled on the SOURCE address like every LDS-DMA tile of this library)
+//     go HBM/L2 -> LDS by DMA into a ring of NB slots; tile t + NB - 1 is issued at the top of iteration t (5 DMA pieces + 4 weight
+//     loads per wave, always in this order), the end of iteration t waits — counted, `s_waitcnt vmcnt(9 (NB - 3))` — until tile t + 2
+//     has landed, one raw s_barrier per k-tile makes it block-visible;
+//   * the weight loads are inline asm (hipcc drains the whole queue with vmcnt(0) at the first use of an ordinary VGPR load issued
+//     beside LDS-DMA): the counted wait statement names the buffer it retires as "+v", which is what orders its MFMAs behind it;
+//   * fragment reads are software-pipelined one k-step ahead ACROSS the barrier (tile t + 1 became visible one barrier earlier),
+//     so a lone wave per SIMD never starts a k-tile with an exposed LDS round trip;
+//   * epilogue: the block's 160 x 128 fp32 tile goes through LDS (the ring, XOR-swizzled instead of padded: exactly 80 KiB) and is
+//     read back as whole row segments by vt_epi_segment (bias / per-head RMSNorm / activation / column scale / residual), the same
+//     arithmetic in the same order as vt_gemm_epilogue.h.
+#include <stdlib.h>
+#include "vt_common.h"
+#include "vt_gemm.h"
+#include "vt_gemm_epilogue.h"
+#include "vt_prof.h"
+#include "vt_host.h"
+#include "../../include/vlatouch.h"
+
+extern int g_vt_gm;
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((ext_vector_type(4))) int int4_t;
+typedef __attribute__((ext_vector_type(16))) float float16_t;
+
+constexpr int BM = 160, BN = 128, BK = 64;
+constexpr int TMW = BM / 32;                     // 32-row MFMA tiles per wave
+constexpr int A_TILE = BM * 128;                 // one k-tile of the activation panel (20 KiB)
+constexpr int OPS = BM / 8 / 4 + 4;              // vector-memory operations per wave per k-tile: 5 DMA pieces + 4 weight loads
+
+template <typename T16> __device__ __forceinline__ float16_t mma32(const int4_t w, const int4_t a, const float16_t c);
+template <> __device__ __forceinline__ float16_t mma32<bf16_t>(const int4_t w, const int4_t a, const float16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, w), __builtin_bit_cast(bf16x8_t, a), c, 0, 0, 0);
+}
+template <> __device__ __forceinline__ float16_t mma32<half_t>(const int4_t w, const int4_t a, const float16_t c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
+}
+
+// one KiB of packed weights -> 4 VGPRs per lane; saddr form: uniform 64-bit base + 32-bit lane offset + immediate.  hipcc does not see
+// this load: its completion is counted by hand (pw_wait).  FIRST: the base SGPRs may come from a VALU readfirstlane -> 5 wait states.
+template <int OFF, bool FIRST>
+__device__ __forceinline__ void pw_wload(int4_t& d, const unsigned voff, const char* sbase) {
+  if constexpr (FIRST) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+}
+// counted wait that retires weight buffer w[0..3] (and everything older in this wave's queue, i.e. its DMA pieces of that k-tile)
+template <int N>
+__device__ __forceinline__ void pw_wait(int4_t (&w)[4]) {
+  asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : [n] "i"(N) : "memory");
+}
+
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
+template <typename T16, typename TC, int NB>
+__global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
+  constexpr int SMEM = NB * A_TILE > BM * BN * 4 ? NB * A_TILE : BM * BN * 4;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];                  // ring of A k-tiles; later the block's fp32 output tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, hk = lane >> 5;
+
+  int bid = blockIdx.x;
+  if ((total_tiles & 7) == 0) bid = (bid & 7) * (total_tiles >> 3) + (bid >> 3);     // XCD b%8 gets a contiguous band
+  const int grp = bid / tiles_per_group;
+  const int t_in = bid - grp * tiles_per_group;
+  const int tiles_m = tiles_per_group / tiles_n;
+  const int sr = t_in / (GM * tiles_n);
+  const int gmr = min(GM, tiles_m - sr * GM);
+  const int r_in = t_in - sr * GM * tiles_n;
+  const int tn = r_in / gmr, tm = sr * GM + (r_in - tn * gmr);
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (long)grp * p.a_gs;
+  const int nk = p.K / BK;
+
+  // activation DMA: piece q = 8 tile rows; wave w issues q = w, w+4, ..., w+16.  lane -> (row, chunk position); it fetches the
+  // chunk whose swizzled position is its own.  Rows beyond M are clamped (computed, never stored).
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)(A + (long)m0 * p.lda), 0, 0x7fffffff, 0x00020000);
+  int asrc[5];
+#pragma unroll
+  for (int e = 0; e < 5; ++e) {
+    const int r = (wave + 4 * e) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    asrc[e] = (int)(((long)(min(m0 + r, p.M - 1) - m0) * p.lda + c * 8) * 2);
+  }
+  // weight stream of this wave: 32-column block n0/32 + wave, K/16 fragments of 1 KiB back to back
+  const char* wbase = reinterpret_cast<const char*>(p.Wp) + ((long)grp * p.w_gs) * 2 + ((long)(n0 / 32 + wave) * (p.K / 16)) * 1024;
+  // (the builtin returns int: widen through unsigned, or a low half with bit 31 set sign-extends into the high half)
+  wbase = reinterpret_cast<const char*>(((unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long)wbase >> 32)) << 32) |
+                                        (unsigned long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)wbase));
+  const unsigned wvoff = lane * 16;
+
+  int4_t wb[NB][4];
+  auto issue = [&](const int kt, auto bc) {
+    constexpr int b = decltype(bc)::value;
+#pragma unroll
+    for (int e = 0; e < 5; ++e)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(smem + b * A_TILE + (wave + 4 * e) * 1024), 16, asrc[e], kt * (BK * 2), 0, 0);
+    const char* sb = wbase + (long)kt * 4096;
+    pw_wload<0, true>(wb[b][0], wvoff, sb);
+    pw_wload<1024, false>(wb[b][1], wvoff, sb);
+    pw_wload<2048, false>(wb[b][2], wvoff, sb);
+    pw_wload<3072, false>(wb[b][3], wvoff, sb);
+  };
+
+  // fragment (32 rows x 16 k) of k-step s of the tile in slot b: lane reads row j*32 + l31, chunk s*2 + hk (swizzled by the row)
+  const int xr = (l31 >> 1) & 7;
+  int foff[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) foff[s] = l31 * 128 + (((s * 2 + hk) ^ xr) * 16);
+  auto frags = [&](int4_t (&f)[TMW], const int b, const int s) {
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) f[j] = *reinterpret_cast<const int4_t*>(smem + b * A_TILE + j * 4096 + foff[s]);
+  };
+
+  float16_t acc[TMW];
+#pragma unroll
+  for (int j = 0; j < TMW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  // prologue: tiles 0 .. NB-2 in flight, tiles 0 and 1 landed and block-visible, fragments of (tile 0, step 0) in registers
+  static_for<NB - 1>([&](auto bc) { if (decltype(bc)::value < nk) issue(decltype(bc)::value, bc); });
+  pw_wait<(NB - 3) * OPS>(wb[0]);
+  pw_wait<(NB - 3) * OPS>(wb[1]);
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  int4_t af[2][TMW];
+  frags(af[0], 0, 0);
+
+  auto sub = [&](const int t, auto uc, auto tailc) {
+    constexpr int U = decltype(uc)::value;
+    constexpr bool TAIL = decltype(tailc)::value;
+    if constexpr (!TAIL || U == 0) issue(t + NB - 1, std::integral_constant<int, (U + NB - 1) % NB>{});
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s < 3) frags(af[(s + 1) & 1], U, s + 1);
+      else if (!TAIL || U < NB - 1) frags(af[0], (U + 1) % NB, 0);
+#pragma unroll
+      for (int j = 0; j < TMW; ++j) acc[j] = mma32<T16>(wb[U][s], af[s & 1][j], acc[j]);
+    }
+    // issue order of the k-tile: MFMA, fragment read, MFMA, ... — every read of step s+1 has five MFMAs (160 clk) to land before its
+    // consumer (left alone, hipcc keeps only two reads in flight and a lone wave per SIMD stalls on lgkmcnt before every MFMA)
+#pragma unroll
+    for (int i = 0; i < 4 * TMW; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // one DS read
+    }
+    // tile t + 2: retire it (and this wave's DMA pieces of it), then make every wave's pieces block-visible
+    if constexpr (!TAIL) pw_wait<(NB - 3) * OPS>(wb[(U + 2) % NB]);
+    else if constexpr (U + 2 < NB) pw_wait<(NB - 3 - U > 0 ? NB - 3 - U : 0) * OPS>(wb[(U + 2) % NB]);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int t = 0;
+  for (; t + NB < nk; t += NB) static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::false_type{}); });
+  static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::true_type{}); });
+
+  // ---------------- epilogue: accumulators -> the block's fp32 tile in LDS [160][128], 16-byte columns XOR-swizzled by the row
+  float* tile = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int j = 0; j < TMW; ++j) {
+    const int m = j * 32 + l31;
+#pragma unroll
+    for (int rq = 0; rq < 4; ++rq) {
+      const int n4 = wave * 8 + rq * 2 + hk;                                  // 16-byte column of n = wave*32 + rq*8 + hk*4 .. +3
+      *reinterpret_cast<float4*>(tile + m * BN + ((n4 ^ (m & 7)) * 4)) = make_float4(acc[j][rq * 4], acc[j][rq * 4 + 1], acc[j][rq * 4 + 2], acc[j][rq * 4 + 3]);
+    }
+  }
+  __syncthreads();
+  // read back: 16 lanes cover 64 columns (= one head) of one row, 4 rows per instruction; wave w takes column half w & 1 of rows (w >> 1) * 80 ..
+  const int half = wave & 1, c4 = lane & 15;
+  const int ncol0 = n0 + half * 64, n = ncol0 + c4 * 4;
+  const bool col_ok = n < p.N;
+  const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
+  const float* hw = nullptr;
+  if (p.hn_w0 && ncol0 < p.hn_c0_end) hw = p.hn_w0;
+  else if (p.hn_w1 && ncol0 >= p.hn_c0_end && ncol0 < p.hn_c1_end) hw = p.hn_w1;
+  TC* Cg = reinterpret_cast<TC*>(p.C) + (long)grp * p.c_gs;
+  const TC* Rg = p.residual ? reinterpret_cast<const TC*>(p.residual) + (long)grp * p.r_gs : nullptr;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b4 = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : zero4;
+  const float4 cs4 = (p.colscale && col_ok) ? *reinterpret_cast<const float4*>(p.colscale + n) : one4;
+  const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
+  const int rbase = (wave >> 1) * (BM / 2) + (lane >> 4);
+  if (p.act != VT_ACT_NONE) {
+#pragma unroll 2
+    for (int it = 0; it < BM / 8; ++it) {
+      const int row = rbase + it * 4;
+      const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
+      vt_epi_segment<TC, 0, true>(p, x, b4, cs4, hw, hw4, Cg, Rg, m0 + row, n, ncol0, col_ok);
+    }
+  } else {
+#pragma unroll 4
+    for (int it = 0; it < BM / 8; ++it) {
+      const int row = rbase + it * 4;
+      const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
+      vt_epi_segment<TC, 0, false>(p, x, b4, cs4, hw, hw4, Cg, Rg, m0 + row, n, ncol0, col_ok);
+    }
+  }
+}
+
+// W [N][K] row-major (ldw) -> fragment order: out[((n/32 * K/16 + k/16) * 64 + (k%16)/8 * 32 + n%32) * 8 + k%8]; one thread per 16-byte chunk
+__global__ void pack_w32_kernel(const uint16_t* __restrict__ W, const long ldw, uint16_t* __restrict__ out, const int N, const int K) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // chunk index in the OUTPUT order
+  const long nchunks = (long)N * K / 8;
+  if (i >= nchunks) return;
+  const int lane = (int)(i & 63);
+  const long frag = i >> 6;
+  const int ks = (int)(frag % (K / 16));
+  const int nt = (int)(frag / (K / 16));
+  const int n = nt * 32 + (lane & 31), k = ks * 16 + (lane >> 5) * 8;
+  *reinterpret_cast<uint4*>(out + i * 8) = *reinterpret_cast<const uint4*>(W + (long)n * ldw + k);
+}
+
+}  // namespace
+
+static int g_vt_pw_nb = 0;      // ring depth 4 | 8 (VLATOUCH_PW_NB, vt_tune(1, .)); 0 = default
+static int g_vt_pw_on = 1;      // VLATOUCH_PW=0 / vt_tune(2, 0) disables the kernel (A/B against gemm_ppk_kernel / gemm_pp256d_kernel)
+
+bool vt_gemm_pw_eligible(const VtGemmParams& p) {
+  static const bool init = [] { const char* e = getenv("VLATOUCH_PW"); const char* nb = getenv("VLATOUCH_PW_NB"); if (nb) g_vt_pw_nb = atoi(nb); if (e) g_vt_pw_on = atoi(e) != 0; return true; }();
+  (void)init;
+  if (!g_vt_pw_on || !p.Wp || !vt_gemm_fast_eligible(p) || p.cmap || p.groups != 1) return false;
+  if (p.N % BN || p.K % (8 * BK) || p.lda >= (1 << 21)) return false;
+  const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN) * p.groups;
+  // one round of the 256 CUs, or several rounds each at least 7/8 full
+  const long rounds = (tiles + 255) / 256;
+  return tiles >= 100 && tiles * 8 >= rounds * 256 * 7;
+}
+
+int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
+  const int tiles_n = p.N / BN, tiles_m = (p.M + BM - 1) / BM;
+  const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
+  const int gm = g_vt_gm > 0 ? g_vt_gm : 4;
+  VtProfScope prof(3, p, s);
+  const bool c16 = p.c_dtype != VT_F32;
+#define VT_PW_GO(T16, TC) do { if (g_vt_pw_nb == 8) hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 8>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); \
+                               else hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 4>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); } while (0)
+  if (p.a_dtype == VT_BF16) { if (c16) VT_PW_GO(bf16_t, bf16_t); else VT_PW_GO(bf16_t, float); }
+  else { if (c16) VT_PW_GO(half_t, half_t); else VT_PW_GO(half_t, float); }
+#undef VT_PW_GO
+  return vt_check_launch();
+}
+
+extern "C" int vt_tune(int knob, int value) {
+  VtGemmParams dummy{};
+  (void)vt_gemm_pw_eligible(dummy);          // environment defaults are read before the first explicit setting
+  if (knob == 1 && (value == 0 || value == 4 || value == 8)) { g_vt_pw_nb = value; return VT_OK; }
+  if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
+  return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
+}
+
+extern "C" int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t stream) {
+  if (!W || !out || N <= 0 || K <= 0 || N % 32 || K % 16 || ldw % 8) return vt_fail(VT_ERR_ARG, "vt_pack_w32: N %% 32, K %% 16, ldw %% 8 must be 0");
+  const long nchunks = (long)N * K / 8;
+  hipLaunchKernelGGL(pack_w32_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)W, ldw, (uint16_t*)out, N, K);
+  return vt_check_launch();
+}

@@ -69,7 +69,7 @@ int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, 
 int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);
 int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
-                    float noise_scale, float d, hipStream_t s);
+                    float noise_scale, float d, float score_eps, int backward, hipStream_t s);
 int vt_k_actnorm(const float* in, float* out, const float* mins, const float* maxs, long n, int dim, float pad, int denorm, hipStream_t s);
 int vt_k_pad_cols(const float* in, int cin, void* out, int odt, int cout, long rows, hipStream_t s);
 int vt_k_place_cols(const void* src, int sdt, long lds_, void* out, int odt, long ldo, int off, int rows, int cols, hipStream_t s);

@@ -364,13 +364,15 @@ __global__ void act_copy_kernel(const TI* __restrict__ in, long ldi, TO* __restr
 }
 
 __global__ void sde_update_kernel(float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ s,
-                                  const float* __restrict__ z, long n, float dt, float gi, float gdg, float eps, float noise_scale, float d) {
-  // bridge_model.py:363-385 in the reference's operation order
+                                  const float* __restrict__ z, long n, float dt, float gi, float gdg, float eps, float noise_scale, float d,
+                                  float score_eps, int backward) {
+  // bridge_model.py:363-385 in the reference's operation order; eps = epsilon(t) of the b term (:369, also when direction='backward'),
+  // score_eps = score_weight * epsilon(t or 1 - t) (:376, :380)
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float sv = s[i] * gi;
   const float b = v[i] - gdg * sv * eps;
-  float xn = x[i] + (b + eps * sv) * dt;
+  float xn = backward ? x[i] - (b - score_eps * sv) * dt : x[i] + (b + score_eps * sv) * dt;
   if (z) xn += noise_scale * (d * z[i]);
   x[i] = xn;
 }
@@ -584,8 +586,8 @@ int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ld
 }
 
 int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
-                    float noise_scale, float d, hipStream_t s) {
-  hipLaunchKernelGGL(sde_update_kernel, g1(n), dim3(256), 0, s, x, v, sc, z, n, dt, gi, gdg, eps, noise_scale, d);
+                    float noise_scale, float d, float score_eps, int backward, hipStream_t s) {
+  hipLaunchKernelGGL(sde_update_kernel, g1(n), dim3(256), 0, s, x, v, sc, z, n, dt, gi, gdg, eps, noise_scale, d, score_eps, backward);
   return vt_check_launch();
 }
 

@@ -39,10 +39,15 @@ __device__ __forceinline__ int clampi(int i, int n) { return i < 0 ? 0 : (i >= n
 
 struct MeanKernel { float k[11]; };
 
-// gray value of pixel (y, x) of a frame: BGR -> gray fixed point, or the single channel
+// gray value of pixel (y, x) of a frame: BGR -> gray fixed point, or the single channel.  `channels` carries the coefficient set in bit 8:
+// clear = OpenCV >= 3.4.2 / 4.x RGB2Gray<uchar> (15-bit: BY15 3735, GY15 19235, RY15 9798, CV_DESCALE(., 15)) — what an unpinned
+// `opencv-python` resolves to today —, set = OpenCV <= 3.4.1 (14-bit table: B2Y 1868, G2Y 9617, R2Y 4899, + 8192 >> 14).  The two differ
+// by one grey level on ~0.3 % of random colour pixels, never on grey ones.
 __device__ __forceinline__ int gray_at(const uint8_t* F, int channels, int W, int y, int x) {
-  const uint8_t* px = F + ((size_t)y * W + x) * channels;
-  return channels == 3 ? ((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14) : px[0];
+  const int ch = channels & 0xff;
+  const uint8_t* px = F + ((size_t)y * W + x) * ch;
+  if (ch != 3) return px[0];
+  return (channels & 0x100) ? ((px[0] * 1868 + px[1] * 9617 + px[2] * 4899 + 8192) >> 14) : ((px[0] * 3735 + px[1] * 19235 + px[2] * 9798 + 16384) >> 15);
 }
 
 // 'HSR' sensor (init_HSR): histogram of the INVERTED gray image, one block per (frame, slab of rows)
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void marker_hist_kernel(const uint8_t* __restr
   __shared__ int h[256];
   h[threadIdx.x] = 0;
   __syncthreads();
-  const uint8_t* F = frames + (size_t)blockIdx.y * H * W * channels;
+  const uint8_t* F = frames + (size_t)blockIdx.y * H * W * (channels & 0xff);
   const int n = H * W;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&h[255 - gray_at(F, channels, W, i / W, i % W)], 1);
   __syncthreads();
@@ -86,7 +91,7 @@ __global__ __launch_bounds__(256) void marker_binary_kernel(const uint8_t* __res
   __shared__ uint8_t ero[EW][EW + 2];
   const int tid = threadIdx.x;
   const int x0 = blockIdx.x * TS, y0 = blockIdx.y * TS;
-  const uint8_t* F = frames + (size_t)blockIdx.z * H * W * channels;
+  const uint8_t* F = frames + (size_t)blockIdx.z * H * W * (channels & 0xff);
   // ---- gray tile: tile position (r, c) <-> image (y0 - 9 + r, x0 - 9 + c), out-of-image positions hold the REFLECT_101 pixel
   for (int e = tid; e < GW * GW; e += 256) {
     const int r = e / GW, c = e - r * GW;
@@ -312,8 +317,10 @@ size_t vt_marker_workspace_bytes(int N, int H, int W, int max_cand) {
 int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H, int W, double min_area, double max_area, int max_cand,
                      int* markers, int* counts, int max_markers, uint8_t* binary_out, void* workspace, vt_stream_t stream) {
   if (!frames || !markers || !counts || !workspace) return vt_fail(VT_ERR_ARG, "vt_marker_detect: null argument");
+  if (mode < 0 || (mode & ~0x100) > 2) return vt_fail(VT_ERR_ARG, "vt_marker_detect: mode 0 (standard), 1 (binary input) or 2 (HSR), + 0x100 for the OpenCV <= 3.4.1 gray coefficients");
+  const int cfmt = channels | (mode & 0x100);      // gray coefficient set travels with the channel count into the kernels
+  mode &= 0xff;
   const int input_is_binary = mode == 1;
-  if (mode < 0 || mode > 2) return vt_fail(VT_ERR_ARG, "vt_marker_detect: mode 0 (standard), 1 (binary input) or 2 (HSR)");
   if (input_is_binary && channels != 1) return vt_fail(VT_ERR_ARG, "vt_marker_detect: a binary input has one channel");
   if ((channels != 1 && channels != 3) || N < 1 || H < 5 || W < 5 || max_cand < 1 || max_markers < 1 || (long)H * W >= (1L << 30))
     return vt_fail(VT_ERR_ARG, "vt_marker_detect: bad shape (channels 1|3, H, W >= 5)");
@@ -333,10 +340,10 @@ int vt_marker_detect(const uint8_t* frames, int channels, int mode, int N, int H
   if (input_is_binary) hipLaunchKernelGGL(marker_nonzero_kernel, dim3((unsigned)(((long)N * HW + 255) / 256)), dim3(256), 0, s, frames, binary, (long)N * HW);
   else if (mode == 2) {
     if (hipMemsetAsync(hist, 0, (size_t)N * 256 * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "vt_marker_detect: memset");
-    hipLaunchKernelGGL(marker_hist_kernel, dim3(32, N), dim3(256), 0, s, frames, channels, H, W, hist);
+    hipLaunchKernelGGL(marker_hist_kernel, dim3(32, N), dim3(256), 0, s, frames, cfmt, H, W, hist);
     hipLaunchKernelGGL(marker_lut_kernel, dim3(N), dim3(64), 0, s, (const int*)hist, HW, lut);
-    hipLaunchKernelGGL(marker_binary_kernel<true>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, channels, H, W, mk, (const uint8_t*)lut, binary);
-  } else hipLaunchKernelGGL(marker_binary_kernel<false>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, channels, H, W, mk, (const uint8_t*)nullptr, binary);
+    hipLaunchKernelGGL(marker_binary_kernel<true>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, cfmt, H, W, mk, (const uint8_t*)lut, binary);
+  } else hipLaunchKernelGGL(marker_binary_kernel<false>, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, N), dim3(256), 0, s, frames, cfmt, H, W, mk, (const uint8_t*)nullptr, binary);
   hipLaunchKernelGGL(marker_label_local_init_kernel, dim3((HW + 255) / 256, N), dim3(256), 0, s, (const uint8_t*)binary, labels, HW);
   hipLaunchKernelGGL(marker_label_merge_kernel, dim3((HW + 255) / 256, N), dim3(256), 0, s, (const uint8_t*)binary, labels, H, W);
   if (hipMemsetAsync(ncand, 0, (size_t)N * 4, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "vt_marker_detect: memset");

@@ -44,6 +44,8 @@ bool vt_gemm_pp_eligible(const VtGemmParams& p);          // vt_gemm_pp.hip: 256
 int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s);
 bool vt_gemm_ppk_eligible(const VtGemmParams& p);         // vt_gemm_ppk.hip: 160 x 128 tile, in-block split-K ping-pong, one round
 int vt_gemm_ppk_launch(const VtGemmParams& p, hipStream_t s);
+bool vt_gemm_pw_eligible(const VtGemmParams& p);          // vt_gemm_pw.hip: 160 x 128 tile, fragment-packed weights streamed global -> VGPR
+int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s);
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s);
 bool vt_gemm_f32r_eligible(const VtGemmParams& p);        // vt_gemm_f32r.hip: exact fp32, 64 x 64 x 32 tiles through an LDS-DMA ring
 int vt_gemm_f32r_launch(const VtGemmParams& p, hipStream_t s);

@@ -34,13 +34,16 @@ namespace {
 struct Blk {
   const float *norm1, *qkv_b, *qn, *kn, *proj_b, *norm2, *cq_b, *ckv_b, *cqn, *ckn, *cproj_b, *norm3, *fc1_b, *fc2_b;
   const void *qkv_w, *proj_w, *cq_w, *ckv_w, *cproj_w, *fc1_w, *fc2_w;
+  // fragment-packed second copies of the per-denoise-step Linears (vt_rdt_set_packed; null = not packed): vt_gemm_pw.hip
+  const void *qkv_wp, *proj_wp, *cq_wp, *cproj_wp, *fc1_wp, *fc2_wp;
 };
 struct Adaptor { int n; const void* w[4]; const float* b[4]; int kin; };
 
 VtGemmParams lin(const void* A, int adt, long lda, const void* W, int cdt, long ldw, const float* b, void* C, int odt, long ldc, int M, int N,
-                 int K, int act) {
+                 int K, int act, const void* Wp = nullptr) {
   VtGemmParams p;
   memset(&p, 0, sizeof(p));
+  p.Wp = Wp;
   p.A = A; p.W = W; p.C = C; p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc;
   p.bias = b; p.act = act; p.groups = 1; p.splitk = 1; p.a_dtype = adt; p.w_dtype = cdt; p.c_dtype = odt;
   return p;
@@ -55,6 +58,7 @@ struct vt_rdt_s {
   Blk blk[64];
   const float *normf, *ffc1_b, *ffc2_b;
   const void *ffc1_w, *ffc2_w;
+  const void* ffc1_wp;
   Adaptor lang, img, state;
 };
 
@@ -91,6 +95,36 @@ int vt_rdt_create(const vt_rdt_desc* desc, const void* const* w, int n, vt_rdt_t
   return VT_OK;
 }
 void vt_rdt_destroy(vt_rdt_t h) { delete h; }
+
+// Fragment-packed second copies of the Linears of the denoise loop (qkv, proj, cross q, cross proj, fc1, fc2 of every block + the final
+// fc1): the caller owns `buf` (vt_rdt_packed_bytes(h) bytes, resident as long as the handle is used); the packing kernels are enqueued
+// on `stream`.  Returns 0 bytes when the configuration has no use for them (fp32 mode, hidden size not a multiple of 512).
+size_t vt_rdt_packed_bytes(vt_rdt_t h) {
+  if (!h || h->d.cdt != VT_BF16 || h->d.hidden % 512) return 0;
+  const size_t DD = (size_t)h->d.hidden * h->d.hidden * 2;
+  return (size_t)h->d.depth * 8 * DD + DD;
+}
+int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream) {
+  if (!h) return vt_fail(VT_ERR_ARG, "vt_rdt_set_packed: null handle");
+  if (!vt_rdt_packed_bytes(h)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_rdt_set_packed: this configuration has no packed weights");
+  if (!buf) return vt_fail(VT_ERR_ARG, "vt_rdt_set_packed: null buffer");
+  const int D = h->d.hidden;
+  const size_t DD = (size_t)D * D * 2;
+  char* o = (char*)buf;
+  auto pk = [&](const void* W, int N, const void** slot) -> int {
+    const int r = vt_pack_w32(W, D, o, N, D, stream);
+    if (r) return r;
+    *slot = o; o += (size_t)(N / D) * DD;
+    return VT_OK;
+  };
+  for (int l = 0; l < h->d.depth; ++l) {
+    Blk& b = h->blk[l];
+    CK(pk(b.qkv_w, 3 * D, &b.qkv_wp)); CK(pk(b.proj_w, D, &b.proj_wp)); CK(pk(b.cq_w, D, &b.cq_wp)); CK(pk(b.cproj_w, D, &b.cproj_wp));
+    CK(pk(b.fc1_w, D, &b.fc1_wp)); CK(pk(b.fc2_w, D, &b.fc2_wp));
+  }
+  CK(pk(h->ffc1_w, D, &h->ffc1_wp));
+  return VT_OK;
+}
 
 namespace {
 inline int lpad64(int L) { return (L + 63) / 64 * 64; }
@@ -294,7 +328,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     // --- self attention
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
-    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE, b.qkv_wp);
       bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
       bool folded = false;
       CK(rgemm(c, p, "rdt qkv", fused ? nullptr : b.qn, D, b.kn, 2 * D, &folded));
@@ -304,33 +338,33 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
         CK(vt_k_headnorm(c.ws + c.w.qkv + (size_t)D * a, d.adt, 3 * D, d.heads, M, b.kn, 1e-6f, d.rms_mode, c.s));
       } }
     CK(attn(c, c.ws + c.w.qkv, 3 * D, c.ws + c.w.qkv + (size_t)D * a, c.ws + c.w.qkv + (size_t)2 * D * a, 3 * D, N, N, nullptr, c.ws + c.w.att));
-    { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.proj_wp);
       p.residual = x; p.ldr = D;
       CK(rgemm(c, p, "rdt proj", nullptr, 0, nullptr, 0, nullptr, b.norm2, &xn_ready)); }
     // --- cross attention against the cached condition K/V
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
-    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE, b.cq_wp);
       bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       bool folded = false;
       CK(rgemm(c, p, "rdt cross q", fused ? nullptr : b.cqn, D, nullptr, D, &folded));
       fused = fused || folded;
       if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
     CK(cross_attn(c, l, lang_mask, N));
-    { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.cproj_wp);
       p.residual = x; p.ldr = D;
       CK(rgemm(c, p, "rdt cross proj", nullptr, 0, nullptr, 0, nullptr, b.norm3, &xn_ready)); }
     // --- FFN (hidden = D, tanh-GELU)
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
-    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
+    { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, b.fc1_wp);
       CK(rgemm(c, p, "rdt fc1")); }
-    { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE);
+    { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.fc2_wp);
       p.residual = x; p.ldr = D;
       CK(rgemm(c, p, "rdt fc2", nullptr, 0, nullptr, 0, nullptr, norm_after, &xn_ready)); }
   }
   if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
-  { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH);
+  { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, c.h->ffc1_wp);
     CK(rgemm(c, p, "rdt final fc1")); }
   { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE);
     CK(rgemm(c, p, "rdt final fc2")); }

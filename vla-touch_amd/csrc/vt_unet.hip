@@ -396,8 +396,8 @@ static int si_schedule(int gamma_type, int epsilon_type, float t, float* gam, fl
   return VT_OK;
 }
 
-int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max, int gamma_type,
-                 int epsilon_type, int sde_type, float* traj, int B, int T, void* workspace, vt_stream_t stream) {
+int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max, int gamma_type,
+                    int epsilon_type, int sde_type, int backward, float score_weight, float* traj, int B, int T, void* workspace, vt_stream_t stream) {
   Ctx c;
   CK(make_ctx(c, h, B, T, workspace, stream));
   if (h->d.nets != 2) return vt_fail(VT_ERR_ARG, "vt_si_sample needs a 2-net handle ({v_net|b_net}, s_net)");
@@ -412,15 +412,26 @@ int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, i
   for (int k = 1; k <= n_steps; ++k) {
     float t = (float)((double)k / (double)n_steps);
     t = fminf(fmaxf(t, 0.001f), 1.0f - 0.001f);        // t_min clip (bridge_model.py:347-348)
-    float gam, gder, ginv, eps;
-    if (si_schedule(gamma_type, epsilon_type, t, &gam, &gder, &ginv, &eps)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_si_sample: unknown gamma/epsilon type");
-    const float noise_scale = dt * sqrtf(2.0f * eps);
+    // direction='backward' (:356-361, :379-382): nets, gamma, gamma', gamma^-1, the noise scale and the score weight at 1 - t; the
+    // epsilon inside b stays at t (:369 reads t_tensor in both directions)
+    const float tn = backward ? 1.0f - t : t;
+    float gam, gder, ginv, eps_n, eps_t, dummy;
+    if (si_schedule(gamma_type, epsilon_type, tn, &gam, &gder, &ginv, &eps_n)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_si_sample: unknown gamma/epsilon type");
+    eps_t = eps_n;
+    if (backward && si_schedule(gamma_type, epsilon_type, t, &dummy, &dummy, &dummy, &eps_t)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_si_sample: unknown gamma/epsilon type");
+    const float noise_scale = dt * sqrtf(2.0f * eps_n);
     // 'vs': b = v - gamma_dot*gamma * (s*gamma_inv) * eps (:369);  'bs': b = b_net output (:306) -> no correction term
     const float gdg = sde_type == 0 ? gder * gam : 0.0f;
-    CK(vt_wrap(film_tables(c, nullptr, t, k > 1, cond), "si film tables"));
+    CK(vt_wrap(film_tables(c, nullptr, tn, k > 1, cond), "si film tables"));
     CK(vt_wrap(trunk(c, x, vs), "si trunk"));
-    CK(vt_k_sde_update(x, vs, vs + n, noise ? noise + (long)(k - 1) * n : nullptr, n, dt, ginv, gdg, eps, noise_scale, beta_max, s));
+    CK(vt_k_sde_update(x, vs, vs + n, noise ? noise + (long)(k - 1) * n : nullptr, n, dt, ginv, gdg, eps_t, noise_scale, beta_max, score_weight * eps_n,
+                       backward ? 1 : 0, s));
     if (traj) { if (hipMemcpyAsync(traj + (long)k * n, x, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "traj copy"); }
   }
   return VT_OK;
+}
+
+int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max, int gamma_type,
+                 int epsilon_type, int sde_type, float* traj, int B, int T, void* workspace, vt_stream_t stream) {
+  return vt_si_sample_ex(h, x, cond, noise, n_steps, beta_max, gamma_type, epsilon_type, sde_type, 0, 1.0f, traj, B, T, workspace, stream);
 }

@@ -108,10 +108,8 @@ class StochasticInterpolants:
         return self._sampler[1]
 
     def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise, record=True):
-        if direction != 'forward':
-            raise NotImplementedError("only the forward direction is used by sample() and implemented here")
-        if score_weight != 1.0:
-            raise NotImplementedError("score_weight != 1.0")
+        if direction not in ('forward', 'backward'):
+            raise NotImplementedError
         if self.gamma_type not in _GAMMA or self.epsilon_type not in _EPS:
             raise NotImplementedError
         n_steps = int(1.0 / delta_t)
@@ -120,7 +118,8 @@ class StochasticInterpolants:
             noise = torch.randn((n_steps,) + tuple(x_initial.shape), dtype=torch.float32, device=dev)
         eng = self._sampler_engine(nets, dev)
         res = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,
-                         gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code)
+                         gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code,
+                         backward=direction == 'backward', score_weight=float(score_weight))
         if not record:       # the hot path: no trajectory buffer, no per-step copies
             return res, None
         xT, traj = res

@@ -65,19 +65,29 @@ class ControllerDataset(torch.utils.data.Dataset):
         if ep is None:
             if len(self._cache) >= self._cache_max:
                 self._cache.pop(next(iter(self._cache)))
-            ep = self._cache[path] = ev.load_episode(path)
+            ep = self._cache[path] = ev.load_episode(path, images=self.use_images)     # camera streams only when windows need them
         return ep
+
+    def _light(self):
+        """Pose / action arrays of every file, one episode alive at a time, outside the window cache (the statistics and the index
+        mapping walk the whole dataset once; the reference reads only these arrays per file for them)."""
+        from vlatouch import eval as ev
+        for path in self.file_paths:
+            yield path, ev.load_episode(path, images=False)
 
     def create_index_mapping(self):
         from vlatouch import eval as ev
         self.episode_indices, self.total_samples = [], 0
-        for file_idx, path in enumerate(self.file_paths):
-            starts = ev.episode_windows(self._episode(path), self.context_frames, self.horizon, self.stride)
+        light = []
+        for file_idx, (path, ep) in enumerate(self._light()):
+            light.append({k: ep[k] for k in ("ee_poses", "gripper_pos", "vla_action") if k in ep})
+            starts = ev.episode_windows(ep, self.context_frames, self.horizon, self.stride)
             if not starts:
                 print(f"Warning: No movement detected in file {path}. Skipping.")
                 continue
             self.episode_indices.extend((file_idx, s) for s in starts)
             self.total_samples += len(starts)
+        self._stats = ev.normalization_stats(light) if light else None       # same pass: the files are read once
 
     def __len__(self):
         return self.total_samples
@@ -89,7 +99,9 @@ class ControllerDataset(torch.utils.data.Dataset):
 
     def get_normalization_stats(self):
         from vlatouch import eval as ev
-        return ev.normalization_stats([self._episode(p) for p in self.file_paths])
+        if getattr(self, "_stats", None) is None:
+            self._stats = ev.normalization_stats(ep for _, ep in self._light())
+        return self._stats
 
 
 class ControllerDataModule:
@@ -115,7 +127,7 @@ class ControllerDataModule:
                   image_size=self.image_size, stride=self.stride)
         self.train_dataset = ControllerDataset(file_paths=train_files, **kw)
         self.val_dataset = ControllerDataset(file_paths=val_files, **kw)
-        self.stats = self.train_dataset.get_normalization_stats()
+        self.stats = self.train_dataset.stats                       # computed once, in the dataset's constructor
 
     def train_dataloader(self):
         return torch.utils.data.DataLoader(self.train_dataset, batch_size=self.batch_size, shuffle=True, num_workers=self.num_workers,

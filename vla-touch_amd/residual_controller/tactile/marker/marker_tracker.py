@@ -29,7 +29,12 @@ MAX_CAND = 1024          # components per frame that may pass the area filter be
 
 
 class EnhancedMarkerTracker:
-    def __init__(self, grid_rows=7, grid_cols=9, calibration_frame=None, gelsight_version='standard', device="cuda"):
+    def __init__(self, grid_rows=7, grid_cols=9, calibration_frame=None, gelsight_version='standard', device="cuda", opencv_gray="cv4"):
+        """opencv_gray (not in the reference, whose cv2 is unpinned): which cv2.cvtColor(BGR2GRAY) arithmetic the device restates — "cv4" =
+        OpenCV >= 3.4.2 / 4.x (15-bit coefficients, what `pip install opencv-python` gives today), "cv3" = OpenCV <= 3.4.1 (14-bit)."""
+        if opencv_gray not in ("cv4", "cv3"):
+            raise ValueError(f"opencv_gray must be 'cv4' or 'cv3', got {opencv_gray!r}")
+        self.opencv_gray = opencv_gray
         self.grid_dims = (grid_rows, grid_cols) if grid_rows and grid_cols else None
         self.expected_markers = grid_rows * grid_cols
         self.baseline_markers = None
@@ -63,7 +68,7 @@ class EnhancedMarkerTracker:
         binary = torch.empty(N, H, W, dtype=torch.uint8, device=self.device) if want_binary else None
         lib = L.lib()
         ws = self._ws.get(lib.vt_marker_workspace_bytes(N, H, W, MAX_CAND))
-        mode = 1 if is_binary else (2 if self.gelsight_version == 'HSR' else 0)
+        mode = (1 if is_binary else (2 if self.gelsight_version == 'HSR' else 0)) | (0x100 if self.opencv_gray == "cv3" else 0)
         L.check(lib.vt_marker_detect(L.ptr(frames), Cc, mode, N, H, W, float(min_area), float(max_area), MAX_CAND, L.ptr(markers), L.ptr(counts),
                                      max_markers, L.ptr(binary), L.ptr(ws), L.stream_ptr(self.device)), "vt_marker_detect")
         return markers, counts, binary

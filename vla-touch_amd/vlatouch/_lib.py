@@ -41,6 +41,7 @@ class GemmParams(C.Structure):
         ("hn_w0", C.c_void_p), ("hn_w1", C.c_void_p), ("hn_c0_end", C.c_int), ("hn_c1_end", C.c_int),
         ("hn_eps", C.c_float), ("hn_mode", C.c_int),
         ("cmap", C.c_int), ("cmap_T", C.c_int),
+        ("Wp", C.c_void_p),
     ]
 
 
@@ -118,6 +119,8 @@ SIGNATURES = {
     "vt_prof_enable": (_I, [_I]),
     "vt_prof_collect": (_I, [_P, _P, _P, _P]),
     "vt_gemm": (_I, [_P, _P]),
+    "vt_pack_w32": (_I, [_P, _L, _P, _I, _I, _P]),
+    "vt_tune": (_I, [_I, _I]),
     "vt_attention": (_I, [_P, _P]),
     "vt_groupnorm": (_I, [_P, _P]),
     "vt_rownorm": (_I, [_P, _I, _L, _P, _I, _L, _P, _P, _I, _I, _F, _I, _P]),
@@ -129,6 +132,7 @@ SIGNATURES = {
     "vt_unet_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_unet_forward": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P, _P]),
     "vt_si_sample": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _I, _P, _P]),
+    "vt_si_sample_ex": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P]),
     "vt_dino_create": (_I, [_P, _P, _I, _P]),
     "vt_dino_destroy": (None, [_P]),
     "vt_dino_num_weights": (_I, [_P]),
@@ -146,6 +150,8 @@ SIGNATURES = {
     "vt_rdt_destroy": (None, [_P]),
     "vt_rdt_num_weights": (_I, [_P]),
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_rdt_packed_bytes": (_Z, [_P]),
+    "vt_rdt_set_packed": (_I, [_P, _P, _P]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vt_rdt_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
     "vt_im2col_t": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

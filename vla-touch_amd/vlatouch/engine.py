@@ -189,8 +189,9 @@ class UNetEngine:
         return out
 
     def sample(self, x0: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], n_steps: int, beta_max: float,
-               record: bool = False, gamma_type: int = 0, epsilon_type: int = 0, sde_type: int = 0):
-        """Forward velocity-score SDE from x0 (normalised actions).  Returns xT (and the n_steps+1 states)."""
+               record: bool = False, gamma_type: int = 0, epsilon_type: int = 0, sde_type: int = 0, backward: bool = False,
+               score_weight: float = 1.0):
+        """Velocity-score / drift-score SDE from x0 (normalised actions).  Returns xT (and the n_steps+1 states)."""
         B, T, D = x0.shape
         x = x0.to(self.device, torch.float32).clone().contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
@@ -199,8 +200,9 @@ class UNetEngine:
             assert tuple(noise.shape) == (n_steps, B, T, D), noise.shape
         traj = torch.empty(n_steps + 1, B, T, D, dtype=torch.float32, device=self.device) if record else None
         ws = self._workspace(B, T)
-        L.check(L.lib().vt_si_sample(self._h, L.ptr(x), L.ptr(cond), L.ptr(noise), n_steps, C.c_float(beta_max), gamma_type, epsilon_type,
-                                     sde_type, L.ptr(traj), B, T, L.ptr(ws), L.stream_ptr(self.device)), "vt_si_sample")
+        L.check(L.lib().vt_si_sample_ex(self._h, L.ptr(x), L.ptr(cond), L.ptr(noise), n_steps, C.c_float(beta_max), gamma_type, epsilon_type,
+                                        sde_type, int(bool(backward)), C.c_float(score_weight), L.ptr(traj), B, T, L.ptr(ws),
+                                        L.stream_ptr(self.device)), "vt_si_sample")
         return (x, traj) if record else x
 
 

@@ -51,15 +51,18 @@ def natural_sort_filenames(files: Sequence[str]) -> List[str]:
     return sorted(files, key=num)
 
 
-def load_episode(path: str) -> Dict[str, np.ndarray]:
+def load_episode(path: str, images: bool = True) -> Dict[str, np.ndarray]:
+    """images=False skips the two camera streams (442 KB per frame each once decoded): statistics, index mapping and image-free
+    training only touch the pose / action / force arrays (controller_dataset.py:172-236 reads just those per file)."""
+    cams = ("camera1_resized", "camera2_resized") if images else ()
     if path.endswith(".npz"):
         z = np.load(path)
-        ep = {k: z[k] for k in z.files}
+        ep = {k: z[k] for k in z.files if images or k not in ("camera1_resized", "camera2_resized", "camera1_images", "camera2_images")}
     else:
         from . import h5lite       # the product's own reader of the reference's LZF-compressed episode files (no h5py needed)
         ep = {}
         with h5lite.File(path, "r") as f:
-            for k in ("ee_poses", "gripper_pos", "vla_action", "camera1_resized", "camera2_resized"):
+            for k in ("ee_poses", "gripper_pos", "vla_action") + cams:
                 if k in f:
                     ep[k] = f[k][:]
             ep["gelsight_force/forces"] = f["gelsight_force"]["forces"][:]
@@ -108,8 +111,9 @@ def make_sample(ep: Dict[str, np.ndarray], start: int, context_frames: int = 2, 
     return out
 
 
-def normalization_stats(episodes: Sequence[Dict[str, np.ndarray]]) -> Dict[str, np.ndarray]:
-    """Per-dimension min/max of expert and VLA actions over whole episodes, gripper/255 (controller_dataset.py:172-236)."""
+def normalization_stats(episodes) -> Dict[str, np.ndarray]:
+    """Per-dimension min/max of expert and VLA actions over whole episodes, gripper/255 (controller_dataset.py:172-236).  `episodes` is any
+    iterable (a generator keeps one episode alive at a time)."""
     amin, amax = np.full(10, np.inf), np.full(10, -np.inf)
     vmin, vmax = np.full(10, np.inf), np.full(10, -np.inf)
     for ep in episodes:

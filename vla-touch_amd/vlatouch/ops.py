@@ -17,7 +17,7 @@ def _es(t: torch.Tensor) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
          colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1,
-         headnorm=None, cmap=None) -> torch.Tensor:
+         headnorm=None, cmap=None, wp: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
     cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout."""
@@ -46,7 +46,18 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         p.hn_eps, p.hn_mode = eps, mode
     if cmap is not None:
         p.cmap, p.cmap_T = cmap
+    if wp is not None:                       # fragment-packed copy of w (pack_w32): lets the dispatcher pick the weights-in-registers tile
+        assert wp.numel() == w.numel() and wp.dtype == w.dtype
+        p.Wp = wp.data_ptr()
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
+    return out
+
+
+def pack_w32(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] 16-bit (N % 32 == 0, K % 16 == 0) -> its copy in MFMA fragment order (vt_pack_w32)."""
+    assert w.dim() == 2 and w.stride(1) == 1 and w.element_size() == 2
+    out = torch.empty(w.numel(), dtype=w.dtype, device=w.device)
+    L.check(L.lib().vt_pack_w32(L.ptr(w), w.stride(0), L.ptr(out), w.shape[0], w.shape[1], L.stream_ptr(w.device)), "vt_pack_w32")
     return out
 
 

@@ -78,6 +78,17 @@ class RdtEngine:
         self._h = C.c_void_p()
         L.check(lib.vt_rdt_create(C.byref(d), L.ptr_array(W), len(W), C.byref(self._h)), "vt_rdt_create")
         self._ws = _Workspace(dev)
+        # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
+        nb = lib.vt_rdt_packed_bytes(self._h)
+        self._packed = None
+        if nb:
+            self._packed = torch.empty(nb, dtype=torch.uint8, device=dev)
+            L.check(lib.vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(dev)), "vt_rdt_set_packed")
+
+    def repack(self):
+        """Re-derive the fragment-packed copies after `_weights` changed in place (e.g. the multi-GPU weight broadcast)."""
+        if self._packed is not None:
+            L.check(L.lib().vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_rdt_set_packed")
 
     def __del__(self):
         try:

@@ -544,7 +544,8 @@ class _Optimizer:
         dev = self.device
         self._st = static
         self._hyper = torch.zeros(4, dtype=F32, device=dev)
-        self._hyper_host = torch.zeros(4, dtype=F32).pin_memory()
+        self._hyper_ring = [torch.zeros(4, dtype=F32).pin_memory() for _ in range(8)]
+        self._hyper_ev = [None] * 8
         for name, p, _ in self._all_params():
             if name not in self._m:
                 self._m[name], self._v[name] = torch.zeros_like(p), torch.zeros_like(p)
@@ -558,11 +559,24 @@ class _Optimizer:
         if getattr(self, "_graph", None) is None:
             raise RuntimeError("call capture(...) first")
         for k, v in inputs.items():
-            self._st[k].copy_(torch.as_tensor(v).reshape(self._st[k].shape), non_blocking=True)
+            v = torch.as_tensor(v)
+            # a pinned host tensor stays the caller's: an asynchronous copy would still be reading it when the caller refills it for the
+            # next step (replays are enqueued back to back), so that one case is copied synchronously
+            self._st[k].copy_(v.reshape(self._st[k].shape), non_blocking=not (v.device.type == "cpu" and v.is_pinned()))
         self.step_count += 1
+        # the step scalars travel through a RING of pinned slots, each guarded by the event recorded behind its last H2D copy: with one
+        # slot, the copy queued for step n would still be waiting behind step n-1's graph when the host writes step n+1's values
+        slot = self.step_count % len(self._hyper_ring)
+        ev = self._hyper_ev[slot]
+        if ev is not None:
+            ev.synchronize()
+        host = self._hyper_ring[slot]
         L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.step_count),
-                                       L.ptr(self._hyper_host)), "vt_train_hyper")
-        self._hyper.copy_(self._hyper_host, non_blocking=True)
+                                       L.ptr(host)), "vt_train_hyper")
+        self._hyper.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._hyper_ev[slot] = ev
         self._graph.replay()
 
 
