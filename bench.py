@@ -121,6 +121,10 @@ def main():
     n_streams = args.streams if args.streams > 0 else (2 if args.workload in ("full", "rdt", "pi_refine", "lstm") else 1)
     noise_bufs = [torch.empty(10, B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
     out_holders = [{} for _ in range(n_streams)]
+    vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
+    xinit_bufs = [torch.empty(B, 64, 128, dtype=torch.float32, device=dev) for _ in range(n_streams)]
+    from vlatouch import ops as _ops
+    rng = _ops.DeviceRng(20250928 + rank, dev)
 
     # ---- RDT-1B chunk generator (config NOT in the reference: upstream RDT-1B values, SURVEY §8a-8 [assumed-upstream])
     rdt = rin = None
@@ -205,14 +209,15 @@ def main():
                 with torch.cuda.stream(side_stream):
                     obs = ctrl.encode_observation(inp["state"], inp["cam1"], inp["cam2"], inp["forces"])
             # a_t = RDT chunk [B, 64, 128] -> the 10 EEF dims of the first T ticks feed the controller (frank_inference_eef.py:495-517)
-            chunk = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"])
+            x0 = rng.normal_(xinit_bufs[slot], round_bf16=args.precision == "bf16")      # the N(0,1) start (rdt_runner.py:136), vt_randn
+            chunk = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x0, return_fp32=True)
             if obs is not None:
                 torch.cuda.current_stream(dev).wait_stream(side_stream)
             out_holder["chunk"] = chunk
             if args.workload == "rdt":
                 return
-            vla = chunk[:, :T, :10].float()
-        noise_buf.normal_()          # the reference's torch.randn_like draws (bridge_model.py:372), on device
+            vla = _ops.slice_cast(chunk, T, 10, out=vla_bufs[slot])       # chunk[:, :T, :10] as fp32, one kernel
+        rng.normal_(noise_buf)       # the reference's torch.randn_like draws (bridge_model.py:372), on device (vt_randn: Philox)
         out_holder["out"] = ctrl.predict(inp["state"], vla, inp["cam1"], inp["cam2"], inp["forces"], noise=noise_buf, obs_cond=obs)
 
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]

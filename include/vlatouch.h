@@ -51,7 +51,8 @@ int vt_gemm(const void* params, vt_stream_t stream);
  * the reference (torch.nn.Linear keeps one layout, models/rdt/blocks.py:144-183); it is the load-time packing of this engine. */
 int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t stream);
 /* A/B tuning knobs of the GEMM dispatcher (tools/, tests): knob 1 = ring depth of the weights-in-registers tile (0 default, 4, 8);
- * knob 2 = that tile on (1) / off (0). */
+ * knob 2 = that tile on (1) / off (0); knob 3 = the small-M tile (csrc/vt_gemm_pws.hip) on / off; knob 4 = its k-split factor (0 = choose);
+ * knob 5 = timing-only ablation of the weights-in-registers tile (0 = off; results are garbage otherwise: tools/gemm_bench_pw.py --abl). */
 int vt_tune(int knob, int value);
 
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
@@ -65,6 +66,13 @@ int vt_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, con
 /* controller_dataset.py:303-346 / :349-384 (padding factor 1.4): out = (de)normalise(in) per last-dim stats. */
 int vt_action_normalize(const float* in, float* out, const float* mins, const float* maxs, long n, int dim,
                         float padding_factor, int denormalize, vt_stream_t stream);
+/* N(0, 1) draws on the device (counter-based Philox4x32-10 + Box-Muller) for callers that do not inject noise: replaces torch.randn
+ * (rdt_runner.py:136) / torch.randn_like (bridge_model.py:372).  state = 2 x uint64 in DEVICE memory {key, next counter}, advanced behind the
+ * draw by a one-thread kernel (a captured graph draws fresh noise at every replay); round_bf16 != 0 rounds the values to the bf16 grid. */
+int vt_randn(float* out, long n, void* state, int round_bf16, vt_stream_t stream);
+/* out [B][T][Dd] fp32 = in[:, :T, :Dd] of in [B][Tin][Din] (idt fp32 / bf16): the slice + cast between the RDT chunk and the controller's
+ * `vla_actions` (frank_inference_eef.py:495-517 does it with tensor indexing). */
+int vt_slice_cast(const void* in, int idt, float* out, int B, int Tin, int Din, int T, int Dd, vt_stream_t stream);
 
 /* ---------------------------------------------------------------- interpolant U-Nets + SDE sampler
  * Replaces InterpolantsConditionalUnet1D / DiffusionConditionalUnet1D.forward
@@ -195,6 +203,9 @@ int vt_rdt_num_weights(const vt_rdt_desc* desc);
 size_t vt_rdt_workspace_bytes(vt_rdt_t h, int B, int lang_len);
 /* Optional fragment-packed second copies of the Linears of the denoise loop (vt_pack_w32 layout; bf16, hidden % 512 == 0): the caller
  * allocates vt_rdt_packed_bytes(h) bytes (0 = not applicable), vt_rdt_set_packed enqueues the packing kernels and keeps the pointers. */
+/* bounds[depth] (host): per block an upper bound of |q . k| * scale of its cross-attention (8 max|q_norm.weight| max|k_norm.weight| for the
+ * mean-square RMSNorm of blocks.py:86-87; 0 = none) -> the cached cross-attention uses a fixed-maximum softmax where the bound is <= 40. */
+int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n);
 size_t vt_rdt_packed_bytes(vt_rdt_t h);
 int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream);
 /* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the

@@ -85,3 +85,72 @@ extern "C" int vt_selftest_mfma(float* out_err, vt_stream_t stream) {
   hipLaunchKernelGGL((mfma_selftest_kernel<float>), dim3(1), dim3(64), 0, (hipStream_t)stream, out_err + 1);
   return vt_check_launch();
 }
+
+// ---------------------------------------------------------------- Gaussian draws on the device (replaces the reference's torch.randn /
+// torch.randn_like draws, rdt_runner.py:136 and bridge_model.py:372, when the caller does not inject its own noise): counter-based
+// Philox4x32-10 (Salmon et al., SC'11) + Box-Muller, four normals per counter.  The (key, counter) pair lives in DEVICE memory
+// (`state` = 2 x uint64: key, next counter) and is advanced by a one-thread kernel behind the draw, so a captured hipGraph yields fresh
+// noise on every replay without a host round trip.
+namespace {
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], const uint32_t k0, const uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1, n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+}
+// out[i] = N(0, 1) (optionally rounded to the bf16 grid: `noisy_action` lives in bf16 in the reference's bf16 mode), 4 values per thread
+__global__ void randn_kernel(float* __restrict__ out, const long n, const unsigned long long* __restrict__ state, const int round_bf16) {
+  const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q * 4 >= n) return;
+  const unsigned long long key = state[0], ctr = state[1] + (unsigned long long)q;
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+  float v[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);       // (0, 1): log never sees 0
+    const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    v[2 * h] = r * cs; v[2 * h + 1] = r * sn;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (round_bf16) v[j] = bf2f(f2bf(v[j]));
+    if (q * 4 + j < n) out[q * 4 + j] = v[j];
+  }
+}
+__global__ void randn_advance_kernel(unsigned long long* state, const unsigned long long by) { state[1] += by; }
+// out[b][t][d] (fp32) = in[b][t][d] for t < T, d < Dd of in [B][Tin][Din] (adt): the slice + cast between the RDT chunk and the controller
+template <typename TI>
+__global__ void slice_cast_kernel(const TI* __restrict__ in, float* __restrict__ out, int B, int Tin, int Din, int T, int Dd) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)B * T * Dd) return;
+  const int d = (int)(i % Dd);
+  const long r = i / Dd;
+  const int t = (int)(r % T), b = (int)(r / T);
+  out[i] = Elem<TI>::to_f(in[((long)b * Tin + t) * Din + d]);
+}
+}  // namespace
+
+extern "C" int vt_randn(float* out, long n, void* state, int round_bf16, vt_stream_t stream) {
+  if (!out || !state || n < 0) return vt_fail(VT_ERR_ARG, "vt_randn: null argument");
+  if (n == 0) return VT_OK;
+  const long quads = (n + 3) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, n, (const unsigned long long*)state, round_bf16);
+  hipLaunchKernelGGL(randn_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)state, (unsigned long long)quads);
+  return vt_check_launch();
+}
+extern "C" int vt_slice_cast(const void* in, int idt, float* out, int B, int Tin, int Din, int T, int Dd, vt_stream_t stream) {
+  if (!in || !out || B < 1 || T < 1 || Dd < 1 || T > Tin || Dd > Din) return vt_fail(VT_ERR_ARG, "vt_slice_cast: bad shape");
+  const long n = (long)B * T * Dd;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  if (idt == VT_BF16) hipLaunchKernelGGL((slice_cast_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in, out, B, Tin, Din, T, Dd);
+  else if (idt == VT_F32) hipLaunchKernelGGL((slice_cast_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)in, out, B, Tin, Din, T, Dd);
+  else return vt_fail(VT_ERR_UNSUPPORTED, "vt_slice_cast: bf16 or fp32 input");
+  return vt_check_launch();
+}

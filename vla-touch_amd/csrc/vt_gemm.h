@@ -36,4 +36,7 @@ struct VtGemmParams {
   // optional second copy of W in MFMA fragment order (vt_pack_w32: [N/32][K/16][64 lanes][8], N % 32 == 0, K % 16 == 0) for the
   // weights-in-registers tile of vt_gemm_pw.hip; null = not available.  W itself stays valid (other tile shapes read it).
   const void* Wp;
+  // scratch of the small-M tile of vt_gemm_pws.hip when it splits K over blocks: fp32 partial slabs [S][M][N] (sk_ws_bytes available) and
+  // one zero-initialised, self-resetting ticket counter per 96 x 64 output tile (sk_cnt_n of them).  Null = that tile keeps S = 1.
+  void* sk_ws; size_t sk_ws_bytes; int* sk_cnt; int sk_cnt_n;
 };

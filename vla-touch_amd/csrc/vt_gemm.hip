@@ -362,6 +362,7 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.taps && (p.cin % epc || p.K != p.taps * p.cin)) return VT_ERR_ARG;
   if (p.splitk < 1 || p.groups < 1) return VT_ERR_ARG;
   if (p.splitk > 1 && p.c_dtype != VT_F32) return VT_ERR_ARG;
+  if (vt_gemm_pws_eligible(p) && (p.M <= 192 || !vt_gemm_fast_eligible(p))) return vt_gemm_pws_launch(p, s);   // small M, frozen packed weights
   if (vt_gemm_fast_eligible(p)) return vt_gemm_fast_launch(p, s);     // large bf16 GEMMs: LDS-DMA pipeline (vt_gemm_fast.hip)
   if (p.hn_w0 || p.hn_w1 || p.cmap) return VT_ERR_UNSUPPORTED;         // fused head-norm / tile-stream output exist only on the fast path
   if (p.a_dtype == VT_BF16 && p.w_dtype == VT_BF16) {

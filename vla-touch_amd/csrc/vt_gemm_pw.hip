@@ -68,7 +68,9 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
   if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
 }
 
-template <typename T16, typename TC, int NB>
+// ABL (timing-only ablations, tools/gemm_bench_pw.py --abl; results are garbage): 1 = no fragment reads after the prologue, 2 = no weight
+// loads after the prologue, 3 = no MFMAs, 4 = no activation DMA after the prologue
+template <typename T16, typename TC, int NB, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
   constexpr int SMEM = NB * A_TILE > BM * BN * 4 ? NB * A_TILE : BM * BN * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];                  // ring of A k-tiles; later the block's fp32 output tile
@@ -110,14 +112,18 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   int4_t wb[NB][4];
   auto issue = [&](const int kt, auto bc) {
     constexpr int b = decltype(bc)::value;
+    if (ABL != 4 || kt < NB - 1) {
 #pragma unroll
-    for (int e = 0; e < 5; ++e)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(smem + b * A_TILE + (wave + 4 * e) * 1024), 16, asrc[e], kt * (BK * 2), 0, 0);
-    const char* sb = wbase + (long)kt * 4096;
-    pw_wload<0, true>(wb[b][0], wvoff, sb);
-    pw_wload<1024, false>(wb[b][1], wvoff, sb);
-    pw_wload<2048, false>(wb[b][2], wvoff, sb);
-    pw_wload<3072, false>(wb[b][3], wvoff, sb);
+      for (int e = 0; e < 5; ++e)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(smem + b * A_TILE + (wave + 4 * e) * 1024), 16, asrc[e], kt * (BK * 2), 0, 0);
+    }
+    if (ABL != 2 || kt < NB - 1) {
+      const char* sb = wbase + (long)kt * 4096;
+      pw_wload<0, true>(wb[b][0], wvoff, sb);
+      pw_wload<1024, false>(wb[b][1], wvoff, sb);
+      pw_wload<2048, false>(wb[b][2], wvoff, sb);
+      pw_wload<3072, false>(wb[b][3], wvoff, sb);
+    }
   };
 
   // fragment (32 rows x 16 k) of k-step s of the tile in slot b: lane reads row j*32 + l31, chunk s*2 + hk (swizzled by the row)
@@ -145,6 +151,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   __builtin_amdgcn_sched_barrier(0);
   int4_t af[2][TMW];
   frags(af[0], 0, 0);
+  if constexpr (ABL == 1) frags(af[1], 0, 1);
 
   auto sub = [&](const int t, auto uc, auto tailc) {
     constexpr int U = decltype(uc)::value;
@@ -152,10 +159,17 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
     if constexpr (!TAIL || U == 0) issue(t + NB - 1, std::integral_constant<int, (U + NB - 1) % NB>{});
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (s < 3) frags(af[(s + 1) & 1], U, s + 1);
-      else if (!TAIL || U < NB - 1) frags(af[0], (U + 1) % NB, 0);
+      if constexpr (ABL != 1) {
+        if (s < 3) frags(af[(s + 1) & 1], U, s + 1);
+        else if (!TAIL || U < NB - 1) frags(af[0], (U + 1) % NB, 0);
+      }
+      if constexpr (ABL != 3) {
 #pragma unroll
-      for (int j = 0; j < TMW; ++j) acc[j] = mma32<T16>(wb[U][s], af[s & 1][j], acc[j]);
+        for (int j = 0; j < TMW; ++j) acc[j] = mma32<T16>(wb[U][s], af[s & 1][j], acc[j]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < TMW; ++j) asm volatile("" : "+v"(af[s & 1][j]), "+v"(wb[U][s]));
+      }
     }
     // issue order of the k-tile: MFMA, fragment read, MFMA, ... — every read of step s+1 has five MFMAs (160 clk) to land before its
     // consumer (left alone, hipcc keeps only two reads in flight and a lone wave per SIMD stalls on lgkmcnt before every MFMA)
@@ -234,6 +248,7 @@ __global__ void pack_w32_kernel(const uint16_t* __restrict__ W, const long ldw, 
 
 }  // namespace
 
+static int g_vt_pw_abl = 0;     // vt_tune(5, k): timing-only ablation k of gemm_pw_kernel<bf16, bf16, 4> (0 = off)
 static int g_vt_pw_nb = 0;      // ring depth 4 | 8 (VLATOUCH_PW_NB, vt_tune(1, .)); 0 = default
 static int g_vt_pw_on = 1;      // VLATOUCH_PW=0 / vt_tune(2, 0) disables the kernel (A/B against gemm_ppk_kernel / gemm_pp256d_kernel)
 
@@ -256,6 +271,14 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
   const bool c16 = p.c_dtype != VT_F32;
 #define VT_PW_GO(T16, TC) do { if (g_vt_pw_nb == 8) hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 8>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); \
                                else hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 4>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); } while (0)
+  if (g_vt_pw_abl && p.a_dtype == VT_BF16 && c16) {
+    const dim3 g(total), b(256);
+    if (g_vt_pw_abl == 1) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 1>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    else if (g_vt_pw_abl == 2) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 2>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    else if (g_vt_pw_abl == 3) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 3>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    else hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 4>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    return vt_check_launch();
+  }
   if (p.a_dtype == VT_BF16) { if (c16) VT_PW_GO(bf16_t, bf16_t); else VT_PW_GO(bf16_t, float); }
   else { if (c16) VT_PW_GO(half_t, half_t); else VT_PW_GO(half_t, float); }
 #undef VT_PW_GO
@@ -267,6 +290,8 @@ extern "C" int vt_tune(int knob, int value) {
   (void)vt_gemm_pw_eligible(dummy);          // environment defaults are read before the first explicit setting
   if (knob == 1 && (value == 0 || value == 4 || value == 8)) { g_vt_pw_nb = value; return VT_OK; }
   if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
+  if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
+  if (knob == 3 || knob == 4) { vt_gemm_pws_tune(knob, value); return VT_OK; }
   return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
 }
 

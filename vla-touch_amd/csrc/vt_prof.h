@@ -46,6 +46,9 @@ bool vt_gemm_ppk_eligible(const VtGemmParams& p);         // vt_gemm_ppk.hip: 16
 int vt_gemm_ppk_launch(const VtGemmParams& p, hipStream_t s);
 bool vt_gemm_pw_eligible(const VtGemmParams& p);          // vt_gemm_pw.hip: 160 x 128 tile, fragment-packed weights streamed global -> VGPR
 int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s);
+bool vt_gemm_pws_eligible(const VtGemmParams& p);         // vt_gemm_pws.hip: M <= 512, 96 x 64 tiles, split-K with an in-kernel ticket reduction
+int vt_gemm_pws_launch(const VtGemmParams& p, hipStream_t s);
+void vt_gemm_pws_tune(int knob, int value);
 int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s);
 bool vt_gemm_f32r_eligible(const VtGemmParams& p);        // vt_gemm_f32r.hip: exact fp32, 64 x 64 x 32 tiles through an LDS-DMA ring
 int vt_gemm_f32r_launch(const VtGemmParams& p, hipStream_t s);

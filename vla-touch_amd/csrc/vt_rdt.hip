@@ -59,6 +59,7 @@ struct vt_rdt_s {
   const float *normf, *ffc1_b, *ffc2_b;
   const void *ffc1_w, *ffc2_w;
   const void* ffc1_wp;
+  float score_bound[64];        // per block: upper bound of |q . k| * scale in its cross-attention (vt_rdt_set_score_bounds), 0 = unknown
   Adaptor lang, img, state;
 };
 
@@ -96,6 +97,16 @@ int vt_rdt_create(const vt_rdt_desc* desc, const void* const* w, int n, vt_rdt_t
 }
 void vt_rdt_destroy(vt_rdt_t h) { delete h; }
 
+// Per-block upper bounds of the scaled cross-attention scores.  cross_attn.q_norm / k_norm are per-head RMS norms (blocks.py:86-87, 112-113):
+// in the mean-square form |q_normed|_2 <= 8 max|w_q| and |k_normed|_2 <= 8 max|w_k|, so |q . k| / 8 <= 8 max|w_q| max|w_k|: the caller (which
+// holds the weights) passes that number per block and the cached cross-attention runs its softmax against it instead of a running maximum
+// (vt_attn_kvt.hip).  0 = no bound (the variance form of timm <= 1.0.8 has none): online softmax.
+int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n) {
+  if (!h || !bounds || n != h->d.depth) return vt_fail(VT_ERR_ARG, "vt_rdt_set_score_bounds: one bound per block");
+  for (int l = 0; l < n; ++l) h->score_bound[l] = bounds[l] > 0.f ? bounds[l] : 0.f;
+  return VT_OK;
+}
+
 // Fragment-packed second copies of the Linears of the denoise loop (qkv, proj, cross q, cross proj, fc1, fc2 of every block + the final
 // fc1): the caller owns `buf` (vt_rdt_packed_bytes(h) bytes, resident as long as the handle is used); the packing kernels are enqueued
 // on `stream`.  Returns 0 bytes when the configuration has no use for them (fp32 mode, hidden size not a multiple of 512).
@@ -129,9 +140,10 @@ int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream) {
 namespace {
 inline int lpad64(int L) { return (L + 63) / 64 * 64; }
 constexpr int RDT_MAX_SPLITK = 16;
+constexpr int RDT_SK_CNT = 4096;
 struct RWs {
   size_t lang_c, img_c, tmpA, tmpB, state_tok, freq_emb, t_emb, emb_tmp, sin, kv_lang, kv_img, x, xn, qkv, q, att, hid, sa_in, sa_tmpA, sa_tmpB,
-      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, total;
+      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, sk_cnt, total;
   size_t kv_lang_blk, kv_img_blk;   // bytes per block
   size_t slab_bytes;                // split-K scratch of the small-batch Linears (0 when M is large enough without it)
   size_t attn_part; int attn_parts; // key-range parts of the cached cross-attention at small batch (1 = off)
@@ -163,6 +175,7 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.noisy = take((size_t)B * d.horizon * d.out_dim * 4); w.noisy_a = take((size_t)B * d.horizon * d.out_dim * a);
   w.slab_bytes = M <= 512 ? (size_t)RDT_MAX_SPLITK * M * 3 * D * 4 : 0;
   w.slab = take(w.slab_bytes);
+  w.sk_cnt = take(RDT_SK_CNT * sizeof(int));    // ticket counters of the small-M tile (vt_gemm_pws.hip), zeroed once per call
   // cached cross-attention: B*H blocks stream a sample's whole key range each; below ~512 blocks split the range (flash-decoding)
   w.attn_parts = 1;
   { const int bh = B * d.heads; if (bh < 512 && N <= 128) { w.attn_parts = 512 / bh; if (w.attn_parts > 16) w.attn_parts = 16; if (w.attn_parts < 1) w.attn_parts = 1; } }
@@ -191,11 +204,17 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
           bool* hn_done = nullptr, const float* next_norm = nullptr, bool* xn_done = nullptr) {
   if (hn_done) *hn_done = false;
   if (xn_done) *xn_done = false;
+  // (frozen, fragment-packed weights at small M: the split GEMM below runs on vt_gemm_pws.hip in its slab mode — p.Wp travels with q)
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int nk = p.K / 64;
   int S = (int)(512 / (tiles64 > 0 ? tiles64 : 1));
   if (S > RDT_MAX_SPLITK) S = RDT_MAX_SPLITK;
   if (S > nk / 2) S = nk / 2;
+  if (p.Wp && S >= 2) {              // vt_gemm_pws.hip (slab mode) wants a power of two that leaves whole 4-k-tile chunks per slice
+    int P = 1;
+    while (P * 2 <= S && P * 2 <= 8 && nk % (P * 2 * 4) == 0) P *= 2;
+    S = P;
+  }
   const bool small = c.w.slab_bytes > 0 && !vt_gemm_fast_eligible(p) && p.M <= 512 && p.K >= 512 && (p.K % 64) == 0 && (p.N % 4) == 0 && !p.hn_w0 &&
                      !p.hn_w1 && p.groups == 1 && p.taps == 0 && S >= 2 && (size_t)S * p.M * p.N * 4 <= c.w.slab_bytes;
   if (!small) return vt_wrap(vt_gemm_launch(p, c.s), what);
@@ -310,6 +329,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
     p.q_bs = (long)N * D; p.q_rs = D; p.o_bs = (long)N * D; p.o_rs = D;
     p.kmask = lang ? lang_mask : nullptr;
     p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(c.B * Lc) / 64; p.scale = 0.125f;
+    p.fixed_max = c.h->score_bound[l];
     if (c.w.attn_parts > 1 && Lc >= 64 * 2 * c.w.attn_parts) { p.parts = c.w.attn_parts; p.part_ws = (float*)(c.ws + c.w.attn_part); }
     return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
   }
@@ -467,6 +487,7 @@ int vt_rdt_forward(vt_rdt_t h, const void* x_tokens, const float* freq, const fl
                    const void* img_c, const uint8_t* lang_mask, void* out, int B, int L, void* workspace, vt_stream_t stream) {
   RCtx c;
   CK(make_rctx(c, h, B, L, workspace, stream));
+  if (hipMemsetAsync(c.ws + c.w.sk_cnt, 0, RDT_SK_CNT * sizeof(int), c.s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "ticket counters");
   const vt_rdt_desc& d = h->d;
   const int D = d.hidden, N = d.horizon + 3, bf = d.adt == VT_BF16;
   // conditions + position embeddings (model.py:150-152)
@@ -501,6 +522,7 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
   const int D = d.hidden, N = d.horizon + 3, Hh = d.horizon, S = d.state_dim, bf = d.adt == VT_BF16, a = c.a;
   if (d.out_dim != S) return vt_fail(VT_ERR_ARG, "vt_rdt_sample: action_dim must equal state_token_dim");
   hipStream_t s = c.s;
+  if (hipMemsetAsync(c.ws + c.w.sk_cnt, 0, RDT_SK_CNT * sizeof(int), s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "ticket counters");
   // ---- once per chunk: adaptors (+pos), condition K/V caches, ctrl-freq embedding, adapted state token
   if (!adapted) {   // predict_action: raw encoder tokens -> adaptors (rdt_runner.py:240-242)
     CK(run_adaptor(c, h->lang, lang_tokens, L, B, c.ws + c.w.lang_c, h->lang_pos, c.ws + c.w.tmpA, c.ws + c.w.tmpB));

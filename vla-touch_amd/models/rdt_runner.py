@@ -189,23 +189,30 @@ class RDTRunner:
         eng = self.engine()
         B = state_traj.shape[0]
         if x_init is None:
-            x_init = torch.randn(B, self.pred_horizon, self.action_dim, dtype=self.dtype, device=eng.device)
+            x_init = self._draw_start(eng, B)
         with torch.no_grad():
             return eng.sample(lang_cond, lang_attn_mask, img_cond, state_traj.reshape(B, -1), action_mask, ctrl_freqs, x_init,
                               num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
                               beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=True)
 
-    def predict_action(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init=None):
+    def _draw_start(self, eng, B):
+        """The reference's `torch.randn(size=(B, horizon, action_dim), dtype=dtype)` start (rdt_runner.py:136): torch's generator, so
+        `torch.manual_seed` governs it as in the reference.  A caller that wants no torch kernel in its step passes `x_init=` drawn by
+        vlatouch.ops.DeviceRng (fp32 storage, values on the dtype's grid: no cast kernels either)."""
+        return torch.randn(B, self.pred_horizon, self.action_dim, dtype=self.dtype, device=eng.device)
+
+    def predict_action(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init=None, return_fp32=False):
         """lang_tokens (B, L, lang_dim), lang_attn_mask (B, L) bool, img_tokens (B, img_len, img_dim), state_tokens (B, 1, state_dim),
-        action_mask (B, 1, action_dim) 0/1 float, ctrl_freqs (B,) -> (B, horizon, action_dim)  (rdt_runner.py:225-250)."""
+        action_mask (B, 1, action_dim) 0/1 float, ctrl_freqs (B,) -> (B, horizon, action_dim)  (rdt_runner.py:225-250).
+        return_fp32 (not in the reference): hand back the engine's fp32 buffer (values on the dtype's grid) instead of casting it."""
         eng = self.engine()
         B = lang_tokens.shape[0]
         if x_init is None:
-            x_init = torch.randn(B, self.pred_horizon, self.action_dim, dtype=self.dtype, device=eng.device)
+            x_init = self._draw_start(eng, B)
         with torch.no_grad():
             return eng.sample(lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init,
                               num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
-                              beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=False)
+                              beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=False, return_fp32=return_fp32)
 
     def compute_loss(self, *a, **k):
         raise NotImplementedError("training is outside this build's scope (inference-only hot path)")

@@ -114,7 +114,8 @@ class StochasticInterpolants:
             raise NotImplementedError
         n_steps = int(1.0 / delta_t)
         dev = x_initial.device if x_initial.device.type == "cuda" else torch.device("cuda")
-        if noise is None:   # the reference's `self.d * torch.randn_like(current_x)` draws, made up-front
+        if noise is None:   # the reference's `self.d * torch.randn_like(current_x)` draws, made up-front (torch's generator: `torch.manual_seed`
+            # governs them as in the reference; a caller that wants no torch kernel in its step passes `noise=` from vlatouch.ops.DeviceRng)
             noise = torch.randn((n_steps,) + tuple(x_initial.shape), dtype=torch.float32, device=dev)
         eng = self._sampler_engine(nets, dev)
         res = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,

@@ -42,6 +42,7 @@ class GemmParams(C.Structure):
         ("hn_eps", C.c_float), ("hn_mode", C.c_int),
         ("cmap", C.c_int), ("cmap_T", C.c_int),
         ("Wp", C.c_void_p),
+        ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("sk_cnt", C.c_void_p), ("sk_cnt_n", C.c_int),
     ]
 
 
@@ -119,6 +120,8 @@ SIGNATURES = {
     "vt_prof_enable": (_I, [_I]),
     "vt_prof_collect": (_I, [_P, _P, _P, _P]),
     "vt_gemm": (_I, [_P, _P]),
+    "vt_randn": (_I, [_P, _L, _P, _I, _P]),
+    "vt_slice_cast": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
     "vt_pack_w32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vt_tune": (_I, [_I, _I]),
     "vt_attention": (_I, [_P, _P]),
@@ -150,6 +153,7 @@ SIGNATURES = {
     "vt_rdt_destroy": (None, [_P]),
     "vt_rdt_num_weights": (_I, [_P]),
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_rdt_set_score_bounds": (_I, [_P, _P, _I]),
     "vt_rdt_packed_bytes": (_Z, [_P]),
     "vt_rdt_set_packed": (_I, [_P, _P, _P]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),

@@ -17,7 +17,8 @@ def _es(t: torch.Tensor) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, *, act: int = L.ACT_NONE,
          colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1,
-         headnorm=None, cmap=None, wp: Optional[torch.Tensor] = None) -> torch.Tensor:
+         headnorm=None, cmap=None, wp: Optional[torch.Tensor] = None, sk_ws: Optional[torch.Tensor] = None,
+         sk_cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
     cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout."""
@@ -49,7 +50,33 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if wp is not None:                       # fragment-packed copy of w (pack_w32): lets the dispatcher pick the weights-in-registers tile
         assert wp.numel() == w.numel() and wp.dtype == w.dtype
         p.Wp = wp.data_ptr()
+    if sk_ws is not None and sk_cnt is not None:      # split-K scratch of the small-M tile: fp32 slab area + zeroed int32 ticket counters
+        assert sk_cnt.dtype == torch.int32
+        p.sk_ws, p.sk_ws_bytes, p.sk_cnt, p.sk_cnt_n = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size(), sk_cnt.data_ptr(), sk_cnt.numel()
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
+    return out
+
+
+class DeviceRng:
+    """Philox key + counter in device memory (vt_randn): N(0,1) draws without torch kernels, graph-replay safe."""
+
+    def __init__(self, seed: int, device="cuda"):
+        self.device = L.require_gpu(device)
+        self.state = torch.tensor([seed & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=self.device)
+
+    def normal_(self, out: torch.Tensor, round_bf16: bool = False) -> torch.Tensor:
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.device.type == "cuda"
+        L.check(L.lib().vt_randn(L.ptr(out), out.numel(), L.ptr(self.state), int(round_bf16), L.stream_ptr(out.device)), "vt_randn")
+        return out
+
+
+def slice_cast(x: torch.Tensor, T: int, D: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B, Tin, Din] (bf16 / fp32, contiguous) -> fp32 [B, T, D] = x[:, :T, :D].float() in one kernel."""
+    assert x.dim() == 3 and x.is_contiguous()
+    B, Tin, Din = x.shape
+    if out is None:
+        out = torch.empty(B, T, D, dtype=torch.float32, device=x.device)
+    L.check(L.lib().vt_slice_cast(L.ptr(x), L.dt_code(x.dtype), L.ptr(out), B, Tin, Din, T, D, L.stream_ptr(x.device)), "vt_slice_cast")
     return out
 
 

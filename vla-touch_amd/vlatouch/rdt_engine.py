@@ -79,14 +79,30 @@ class RdtEngine:
         L.check(lib.vt_rdt_create(C.byref(d), L.ptr_array(W), len(W), C.byref(self._h)), "vt_rdt_create")
         self._ws = _Workspace(dev)
         # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
+        self._depth, self._rms_mode = depth, rms_mode
+        self._set_score_bounds()
         nb = lib.vt_rdt_packed_bytes(self._h)
         self._packed = None
         if nb:
             self._packed = torch.empty(nb, dtype=torch.uint8, device=dev)
             L.check(lib.vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(dev)), "vt_rdt_set_packed")
 
+    def _set_score_bounds(self):
+        """|q . k| / 8 <= 8 max|w_q| max|w_k| for the mean-square per-head RMSNorm of cross_attn.q_norm / k_norm (blocks.py:86-87, 112-113)
+        (+2 %: the normed q / k are stored in bf16): lets the cached cross-attention drop its running maximum.  The variance form has no
+        such bound -> 0 (online softmax).  Weight order per block: see csrc/vt_rdt.hip (cq_norm at +12, ck_norm at +13)."""
+        bounds = (C.c_float * self._depth)()
+        if self._rms_mode == "meansq" and self.dtype == torch.bfloat16:
+            for i in range(self._depth):
+                base = 11 + 21 * i
+                wq, wk = self._weights[base + 12], self._weights[base + 13]
+                bounds[i] = 8.0 * 1.02 * float(wq.abs().max()) * float(wk.abs().max())
+        L.check(L.lib().vt_rdt_set_score_bounds(self._h, bounds, self._depth), "vt_rdt_set_score_bounds")
+
     def repack(self):
-        """Re-derive the fragment-packed copies after `_weights` changed in place (e.g. the multi-GPU weight broadcast)."""
+        """Re-derive what was computed from `_weights` at load time after they changed in place (e.g. the multi-GPU weight broadcast):
+        the fragment-packed copies and the cross-attention score bounds."""
+        self._set_score_bounds()
         if self._packed is not None:
             L.check(L.lib().vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_rdt_set_packed")
 
@@ -140,7 +156,7 @@ class RdtEngine:
 
     def sample(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init, *, num_inference_steps: int,
                num_train_timesteps: int = 1000, beta_schedule: str = "squaredcos_cap_v2", prediction_type: str = "sample",
-               adapted: bool = False) -> torch.Tensor:
+               adapted: bool = False, return_fp32: bool = False) -> torch.Tensor:
         """RDTRunner.predict_action (adapted=False: raw encoder tokens) / conditional_sample (adapted=True: tokens already
         projected to hidden size); x_init = the N(0,1) start [B, horizon, action_dim]."""
         if prediction_type not in ("sample", "epsilon"):
@@ -179,4 +195,4 @@ class RdtEngine:
         L.check(L.lib().vt_rdt_sample(self._h, L.ptr(lang_tokens), L.ptr(mask), L.ptr(img_tokens), L.ptr(state_tokens), L.ptr(action_mask),
                                       L.ptr(ctrl_freqs), L.ptr(x_init), len(ts), ts_c, coef_c, int(prediction_type == "sample"), int(adapted), L.ptr(out), B, Llang,
                                       L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)), "vt_rdt_sample")
-        return out.to(dt)
+        return out if return_fp32 else out.to(dt)
