@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--res", type=int, default=224)
     ap.add_argument("--dino", default="base", choices=["small", "base"])
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "lstm", "marker", "train", "train_lstm"],
+    ap.add_argument("--workload", default="full", choices=["full", "pi_refine", "dino_mlp", "rdt", "siglip", "robot", "lstm", "marker", "train", "train_lstm"],
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
@@ -118,7 +118,7 @@ def main():
     setup_s = time.time() - t0
     B, T = args.batch, args.horizon
     inp = synth_inputs(B, T, args.res, 1234 + rank, dev)
-    n_streams = args.streams if args.streams > 0 else (2 if args.workload in ("full", "rdt", "pi_refine", "lstm") else 1)
+    n_streams = args.streams if args.streams > 0 else (2 if args.workload in ("full", "rdt", "pi_refine", "lstm", "robot") else 1)
     noise_bufs = [torch.empty(10, B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
     out_holders = [{} for _ in range(n_streams)]
     vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
@@ -130,7 +130,7 @@ def main():
     rdt = rin = None
     RDT1B = dict(hidden=2048, depth=28, heads=32, horizon=64, action_dim=128, lang_token_dim=4096, img_token_dim=1152,
                  state_token_dim=128, max_lang_cond_len=1024, img_cond_len=4374)
-    if args.workload in ("full", "rdt"):
+    if args.workload in ("full", "rdt", "robot"):
         from models.rdt_runner import RDTRunner
         rdt_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
         cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": "meansq"}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
@@ -173,7 +173,7 @@ def main():
         mk.calibrate(base_frames[0])
         args.no_graph = True                                                # the stream API returns host arrays (counts are read back)
     sig = sig_px = None
-    if args.workload == "siglip":       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
+    if args.workload in ("siglip", "robot"):       # the RDT image tower on the 6 frames of every chunk (so400m, 384x384, 729 tokens each)
         from vlatouch.engine import SiglipEngine
         c = synth.SIGLIP_CONFIGS["so400m"]
         wdt = torch.float32
@@ -181,6 +181,8 @@ def main():
         sig = SiglipEngine({k: v.cpu() for k, v in ssd.items()}, heads=c["heads"], precision="fp16" if args.precision == "bf16" else "fp32", device=dev)
         del ssd
         sig_px = (2.0 * torch.rand(6 * B, 3, 384, 384, device=dev) - 1.0)
+        if args.workload == "robot":
+            tok_bufs = [torch.empty(6 * B, 729, 1152, dtype=rdt_dtype, device=dev) for _ in range(n_streams)]
     setup_s = time.time() - t0
 
     def step(slot=0):
@@ -191,6 +193,18 @@ def main():
             return
         if args.workload == "siglip":
             out_holder["out"] = sig.forward(sig_px)
+            return
+        if args.workload == "robot":
+            # the robot step (franka_model_eef.py:283-313 + frank_inference_eef.py:495-533): 6 camera frames per chunk through the SigLIP tower
+            # -> image tokens (cast to the RDT dtype) -> RDT chunk -> first T ticks x 10 EEF dims -> DINOv2 x2 + MLP + interpolant SDE
+            tok = sig.forward(sig_px)                                            # [6B, 729, 1152] fp32
+            img_tok = _ops.cast(tok, rdt_dtype, out=tok_bufs[slot]).view(B, 6 * tok.shape[1], tok.shape[2])
+            x0 = rng.normal_(xinit_bufs[slot], round_bf16=args.precision == "bf16")
+            chunk = rdt.predict_action(rin["lang"], rin["mask"], img_tok, rin["state"], rin["amask"], rin["freq"], x_init=x0, return_fp32=True)
+            out_holder["chunk"] = chunk
+            vla_r = _ops.slice_cast(chunk, T, 10, out=vla_bufs[slot])
+            rng.normal_(noise_buf)
+            out_holder["out"] = ctrl.predict(inp["state"], vla_r, inp["cam1"], inp["cam2"], inp["forces"], noise=noise_buf)
             return
         if args.workload == "marker":
             out_holder["out"] = mk.track_frames(mk_frames)
@@ -307,6 +321,10 @@ def main():
         "dino_mlp": ("encoded observations/sec", "dino_mlp = BASELINE configs[1]: 2x DINOv2-%s @%d + state/force MLP" % (args.dino, args.res)),
         "lstm": ("refined action chunks/sec (LSTM residual head, no RDT chunk generation)", "lstm (SURVEY 8a-7): 2x DINOv2-%s CLS @%d + obs MLP + "
                  "%d sequential ticks of force MLP -> 2-layer LSTM -> residual head per chunk" % (args.dino, args.res, T)),
+        "robot": ("refined action chunks/sec (SigLIP image tower + RDT-1B chunk + DINOv2 x2 + pi_I)",
+                  "robot = the reference's whole robot step (franka_model_eef.py:283-313, frank_inference_eef.py:495-533): 6 x 384x384 frames per chunk -> "
+                  "SigLIP-so400m tower -> 4374 image tokens -> RDT-1B chunk (%d-step DPM-Solver++, %d lang tokens) -> first %d ticks x 10 EEF dims -> 2x "
+                  "DINOv2-%s @%d + MLP + 10-step interpolant SDE; batch %d chunks" % (args.rdt_steps, args.lang_len, T, args.dino, args.res, B)),
         "siglip": ("chunks' worth of image tokens/sec (6 frames per chunk)", "siglip (SURVEY 8f-1): SigLIP-so400m-patch14-384 tower, 6 x 384x384 frames per "
                    "chunk -> 6 x 729 x 1152 image tokens, batch %d chunks (%d images per step)" % (B, 6 * B)),
         "marker": ("GelSight frames/sec (marker displacements + force estimate m_t)", "marker (SURVEY 8f-3): %d frames of 240x320x3 per step: blur -> adaptive "
@@ -379,8 +397,8 @@ def main():
 
     r_pp = roof(2, "gemm_pp256d_kernel (256x256x64 ping-pong tile, deep-prefetch schedule, 16-bit MFMA: fused condition K|V projections, image adaptor, "
                    "RDT qkv projections, DINOv2 Linears)", "gemm_pp256")
-    r_gl = roof(3, "gemm_ppk_kernel (160x128x64 in-block split-K ping-pong tile; with the few gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows)",
-                "gemm_ppk")
+    r_gl = roof(3, "gemm_pw_kernel (160x128x64 tile, frozen fragment-packed weights streamed global -> VGPR, activations through an LDS-DMA ring; with the few "
+                   "gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows, incl. the fused qkv projection)", "gemm_pw")
     r_at = None
     if prof.get(4, (0, 0, 0, 0))[3] > 0 and prof[4][0] > 0:
         ms_, fl_, by_, n_ = prof[4]

@@ -52,7 +52,8 @@ int vt_gemm(const void* params, vt_stream_t stream);
 int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t stream);
 /* A/B tuning knobs of the GEMM dispatcher (tools/, tests): knob 1 = ring depth of the weights-in-registers tile (0 default, 4, 8);
  * knob 2 = that tile on (1) / off (0); knob 3 = the small-M tile (csrc/vt_gemm_pws.hip) on / off; knob 4 = its k-split factor (0 = choose);
- * knob 5 = timing-only ablation of the weights-in-registers tile (0 = off; results are garbage otherwise: tools/gemm_bench_pw.py --abl). */
+ * knob 5 = timing-only ablation of the weights-in-registers tile (0 = off; results are garbage otherwise: tools/gemm_bench_pw.py --abl);
+ * knob 6 = fixed-maximum softmax of the cached cross-attention on (1) / off (0: always the online form). */
 int vt_tune(int knob, int value);
 
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
@@ -73,6 +74,9 @@ int vt_randn(float* out, long n, void* state, int round_bf16, vt_stream_t stream
 /* out [B][T][Dd] fp32 = in[:, :T, :Dd] of in [B][Tin][Din] (idt fp32 / bf16): the slice + cast between the RDT chunk and the controller's
  * `vla_actions` (frank_inference_eef.py:495-517 does it with tensor indexing). */
 int vt_slice_cast(const void* in, int idt, float* out, int B, int Tin, int Din, int T, int Dd, vt_stream_t stream);
+/* out [rows][cols] (odt) = in (idt), element-wise dtype conversion with row strides (fp32 / bf16 / fp16): `.to(dtype)` between pipeline
+ * stages, e.g. SigLIP image tokens -> RDTRunner.predict_action's img_tokens (franka_model_eef.py:286-288). */
+int vt_cast(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, vt_stream_t stream);
 
 /* ---------------------------------------------------------------- interpolant U-Nets + SDE sampler
  * Replaces InterpolantsConditionalUnet1D / DiffusionConditionalUnet1D.forward

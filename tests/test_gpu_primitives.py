@@ -290,3 +290,145 @@ def test_fp32_ring_conv_edges(dev, cfg):
     else:
         slabs = ops.conv1d_cl(x, wp, None, taps=k, cin=cin, tout=tout, stride=stride, off0=-pad, splitk=sk)
         assert rel_err(slabs.sum(0), ref) < 2e-6
+
+
+# ---------------------------------------------------------------------------------------- round 3: frozen, fragment-packed weights
+def _ref_linear(a, w, bias, hw, act, res):
+    ref = a.float() @ w.float().t() + bias
+    if hw is not None:
+        M, N = ref.shape
+        x = ref.view(M, N // 64, 64)
+        ref = (x * torch.rsqrt((x * x).mean(-1, keepdim=True) + 1e-6) * hw).reshape(M, N)
+    ref = ACTS[act](ref)
+    return ref if res is None else ref + res.float()
+
+
+@pytest.mark.parametrize("M,N", [(2144, 2048), (2100, 2048), (2144, 6144), (3000, 2048)])
+@pytest.mark.parametrize("variant", ["bf16", "bf16_gelu", "bf16_headnorm", "f32_residual"])
+def test_gemm_packed_weights_tile(dev, M, N, variant):
+    """vt_gemm_pw.hip (weights streamed global -> VGPR from the vt_pack_w32 copy): both ring depths against the torch product and against each
+    other (bit-equal: the ring depth changes the schedule, not the arithmetic); M % 160 != 0 exercises the clamped last row tile;
+    (3000, 2048) = 19 x 16 tiles is not a whole round -> the dispatcher must keep the old tiles (same result either way)."""
+    from vlatouch import ops, _lib as L
+    K = 2048
+    a = rnd((M, K), 11, dev, torch.bfloat16)
+    w = rnd((N, K), 12, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 13, dev)
+    wp = ops.pack_w32(w)
+    hw = (1.0 + 0.1 * rnd((64,), 14, dev)) if variant == "bf16_headnorm" else None
+    odt = torch.float32 if variant == "f32_residual" else torch.bfloat16
+    res = rnd((M, N), 15, dev, odt) if variant == "f32_residual" else None
+    act = 2 if variant == "bf16_gelu" else 0
+    kw = dict(act=act, residual=res, out_dtype=odt, headnorm=(hw, N, None, N, 1e-6, L.NORM_RMS_MEANSQ) if hw is not None else None)
+    lib = L.lib()
+    try:
+        outs = []
+        for nb in (4, 8):
+            lib.vt_tune(1, nb)
+            outs.append(ops.gemm(a, w, bias, wp=wp, **kw))
+        lib.vt_tune(2, 0)
+        old = ops.gemm(a, w, bias, wp=wp, **kw)
+    finally:
+        lib.vt_tune(1, 0); lib.vt_tune(2, 1)
+    ref = _ref_linear(a, w, bias, hw, act, res)
+    tol = 2e-4 if odt == torch.float32 else 1e-2
+    assert torch.equal(outs[0], outs[1])
+    assert rel_err(outs[0], ref) < tol, rel_err(outs[0], ref)
+    assert rel_err(old, ref) < tol
+
+
+def test_pack_w32_layout(dev):
+    """vt_pack_w32: out[((n/32 * K/16 + k/16) * 64 + (k%16)/8 * 32 + n%32) * 8 + k%8] = W[n][k]."""
+    from vlatouch import ops
+    N, K = 96, 80
+    w = torch.arange(N * K, dtype=torch.float32).reshape(N, K).to(torch.bfloat16).to(dev)     # values < 2^13 are exact in bf16? no: use indices mod 256
+    w = (torch.arange(N * K).reshape(N, K) % 251).to(torch.bfloat16).to(dev)
+    got = ops.pack_w32(w).cpu().float().reshape(N // 32, K // 16, 2, 32, 8)
+    want = w.cpu().float().reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("M", [1, 67, 96, 134, 500])
+@pytest.mark.parametrize("variant", ["bf16_headnorm", "f32_residual", "bf16_gelu"])
+def test_gemm_small_m_packed_weights_tile(dev, M, variant):
+    """vt_gemm_pws.hip: direct mode (S = 1, full epilogue), the in-launch ticket reduction (S = 2, 4, 8; deterministic: a second launch is
+    bit-equal, the counters reset themselves) and the slab mode behind the generic split-K contract."""
+    from vlatouch import ops, _lib as L
+    N, K = 2048, 2048
+    a = rnd((M, K), 21, dev, torch.bfloat16)
+    w = rnd((N, K), 22, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 23, dev)
+    wp = ops.pack_w32(w)
+    hw = (1.0 + 0.1 * rnd((64,), 24, dev)) if variant == "bf16_headnorm" else None
+    odt = torch.float32 if variant == "f32_residual" else torch.bfloat16
+    res = rnd((M, N), 25, dev, odt) if variant == "f32_residual" else None
+    act = 2 if variant == "bf16_gelu" else 0
+    kw = dict(act=act, residual=res, out_dtype=odt, headnorm=(hw, N, None, N, 1e-6, L.NORM_RMS_MEANSQ) if hw is not None else None)
+    ref = _ref_linear(a, w, bias, hw, act, res)
+    tol = 2e-4 if odt == torch.float32 else 1e-2
+    ws = torch.empty(8 * M * N, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(4096, dtype=torch.int32, device=dev)
+    lib = L.lib()
+    try:
+        for S in (1, 2, 4, 8):
+            lib.vt_tune(4, S)
+            o1 = ops.gemm(a, w, bias, wp=wp, sk_ws=ws, sk_cnt=cnt, **kw)
+            o2 = ops.gemm(a, w, bias, wp=wp, sk_ws=ws, sk_cnt=cnt, **kw)
+            assert torch.equal(o1, o2), S
+            assert rel_err(o1, ref) < tol, (S, rel_err(o1, ref))
+        assert int(cnt.abs().sum()) == 0
+        lib.vt_tune(4, 0)
+        pre = a.float() @ w.float().t()
+        for S in (2, 8):
+            slabs = ops.gemm(a, w, None, wp=wp, splitk=S)
+            assert slabs.shape == (S, M, N) and rel_err(slabs.sum(0), pre) < 2e-5
+    finally:
+        lib.vt_tune(4, 0)
+
+
+def test_gemm_rowsplit_keeps_fused_headnorm(dev):
+    """A head-norm-fused GEMM whose M lands in the exact-row-split window of the 256-square tile (M % 256 in 1..64 at a round-crossing tile
+    count: 8193 rows x 6144 columns = 33 x 24 tiles) must not be split (the <= 64-row remainder has no fused-head-norm tile)."""
+    from vlatouch import ops, _lib as L
+    M, N, K = 8193, 6144, 512
+    a = rnd((M, K), 31, dev, torch.bfloat16)
+    w = rnd((N, K), 32, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 33, dev)
+    hw = 1.0 + 0.1 * rnd((64,), 34, dev)
+    out = ops.gemm(a, w, bias, headnorm=(hw, N, None, N, 1e-6, L.NORM_RMS_MEANSQ))
+    assert rel_err(out, _ref_linear(a, w, bias, hw, 0, None)) < 1e-2
+
+
+def test_device_rng_slice_cast_and_cast(dev):
+    from vlatouch import ops
+    rng = ops.DeviceRng(1234, dev)
+    x = torch.empty(1 << 20, dtype=torch.float32, device=dev)
+    rng.normal_(x)
+    y = torch.empty_like(x)
+    rng.normal_(y)                                                  # the counter advanced on the device: a different draw
+    assert not torch.equal(x, y)
+    for v in (x, y):
+        assert abs(float(v.mean())) < 5e-3 and abs(float(v.std()) - 1.0) < 5e-3
+        assert abs(float((v ** 4).mean()) - 3.0) < 0.05            # kurtosis of a Gaussian
+    assert abs(float((x * y).mean())) < 5e-3
+    again = ops.DeviceRng(1234, dev).normal_(torch.empty_like(x))
+    assert torch.equal(again, x)                                    # counter-based: same key + counter -> same values
+    z = ops.DeviceRng(7, dev).normal_(torch.empty(1001, dtype=torch.float32, device=dev), round_bf16=True)
+    assert torch.equal(z, z.to(torch.bfloat16).float())
+    # replayed from a captured graph the draw advances without host involvement
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    buf = torch.empty(4096, dtype=torch.float32, device=dev)
+    with torch.cuda.stream(s):
+        rng.normal_(buf)
+        s.synchronize()
+        with torch.cuda.graph(g, stream=s):
+            rng.normal_(buf)
+        g.replay(); s.synchronize(); first = buf.clone()
+        g.replay(); s.synchronize()
+    assert not torch.equal(first, buf)
+    c = rnd((3, 64, 128), 41, dev, torch.bfloat16)
+    assert torch.equal(ops.slice_cast(c, 16, 10), c[:, :16, :10].float())
+    f = rnd((5, 37, 24), 42, dev)
+    assert torch.equal(ops.cast(f, torch.bfloat16), f.to(torch.bfloat16))
+    assert torch.equal(ops.cast(f.to(torch.bfloat16), torch.float32), f.to(torch.bfloat16).float())

@@ -254,3 +254,37 @@ def test_engine_rejects_wrong_shapes():
         m(ri["x"][:, :-1], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"])
     with pytest.raises(ValueError):
         m(ri["x"], ri["freq"], ri["t"], ri["lang_c"], ri["img_c"][:, 1:])
+
+
+@pytest.mark.parametrize("B", [1, 4])
+def test_cross_attention_fixed_maximum_matches_online_softmax(B):
+    """The cached cross-attention with the load-time score bound (softmax against a FIXED maximum, vt_attn_kvt.hip) against its online form
+    (vt_tune(6, 0)): same chunk within bf16 rounding of the attention output; B = 1 also takes the key-range-parts + combine path.  With the
+    q / k norm gains scaled so that the bound exceeds 40 the launcher must fall back to the online form (bit-equal to it)."""
+    from vlatouch import _lib as L
+    cfg = cases.RDT_WIDE
+    r = make_runner(cfg, torch.bfloat16)
+    ri = {k: v.to("cuda:0") for k, v in cases.rdt_inputs(cfg, B, 20, seed=5, dtype=torch.bfloat16).items()}
+    args = (ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"])
+    lib = L.lib()
+    eng = r.engine()
+    bounds = [8.0 * 1.02 * float(eng._weights[11 + 21 * i + 12].abs().max()) * float(eng._weights[11 + 21 * i + 13].abs().max()) for i in range(cfg["depth"])]
+    assert 0 < max(bounds) <= 40, bounds
+    try:
+        fixed = r.predict_action(*args, x_init=ri["x_init"]).float()
+        lib.vt_tune(6, 0)
+        online = r.predict_action(*args, x_init=ri["x_init"]).float()
+        lib.vt_tune(6, 1)
+        scale = float(online.abs().max())
+        assert err(fixed, online.cpu().numpy()) <= 1e-2 * scale, (err(fixed, online.cpu().numpy()), scale)
+        # gains x 3 on both norms: bound x 9 > 40 -> online form regardless of the knob
+        for i in range(cfg["depth"]):
+            eng._weights[11 + 21 * i + 12].mul_(3.0)
+            eng._weights[11 + 21 * i + 13].mul_(3.0)
+        eng.repack()
+        big_fixed = r.predict_action(*args, x_init=ri["x_init"]).float()
+        lib.vt_tune(6, 0)
+        big_online = r.predict_action(*args, x_init=ri["x_init"]).float()
+        assert torch.equal(big_fixed, big_online)
+    finally:
+        lib.vt_tune(6, 1)

@@ -154,3 +154,12 @@ extern "C" int vt_slice_cast(const void* in, int idt, float* out, int B, int Tin
   else return vt_fail(VT_ERR_UNSUPPORTED, "vt_slice_cast: bf16 or fp32 input");
   return vt_check_launch();
 }
+
+// out[rows][cols] (odt, row stride ldo) = in[rows][cols] (idt, row stride ldi): dtype conversion between pipeline stages (e.g. the fp32 image
+// tokens of the SigLIP tower -> the bf16 `img_tokens` of RDTRunner.predict_action; franka_model_eef.py:286-288 does `.to(dtype)`)
+extern "C" int vt_cast(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, vt_stream_t stream) {
+  if (!in || !out || rows < 1 || cols < 1) return vt_fail(VT_ERR_ARG, "vt_cast: bad argument");
+  const int r = vt_k_act_copy(in, idt, ldi, out, odt, ldo, rows, cols, VT_ACT_NONE, (hipStream_t)stream);
+  if (r) vt_fail(r, "vt_cast: unsupported dtype pair");
+  return r;
+}

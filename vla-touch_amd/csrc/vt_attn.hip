@@ -7,6 +7,7 @@
 // The k-index -> key assignment inside a 32-key block is (j>>2)*16 + g*4 + (j&3), which makes the P fragment
 // exactly the lane's own S registers (no cross-lane movement); Vt is read with the same assignment.
 // Online softmax state (m, l) lives per q row, replicated over the 4 lanes sharing lane&15.
+#include <stdlib.h>
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -214,6 +215,177 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
   }
 }
 
+// ---- 16-bit self-attention with DMA-staged, double-buffered K / V tiles (DINOv2 257 tokens, SigLIP 729 tokens x 72-wide heads padded to 96, RDT
+// self-attention).  Same arithmetic and fragment conventions as attn_kernel above; what changes is how the tiles reach the MFMAs:
+//   * K and V tiles (64 keys) go HBM/L2 -> LDS by DMA (16 B per lane, 8 rows x 128 B per wave instruction, XOR swizzle on the SOURCE address),
+//     BOTH row-major [key][d] — attn_kernel transposed V through registers with eight 2-byte LDS stores per 16-byte chunk, which alone cost
+//     more LDS instructions than everything else in the tile;
+//   * the Vt fragment (4 consecutive keys of one d column) is read from the row-major V tile with ds_read_b64_tr_b16: the 16 lanes of a lane
+//     group address a [4 keys][16 d] block (lane i: key i/4, d columns (i%4)*4 .. +3) and the hardware hands lane i the 4 keys of column i;
+//   * two LDS stages: the DMA of tile t+1 is issued before the MFMAs of tile t, waits are counted (vmcnt) and the barriers raw.
+// No key mask here (masked calls keep attn_kernel).  Keys past Nk in the last tile are clamped loads, masked in the softmax.
+typedef __attribute__((address_space(3))) void lds_void_a;
+typedef const __attribute__((address_space(1))) void glb_void_a;
+typedef __attribute__((ext_vector_type(4))) short short4_t;
+
+template <typename T, int HD>
+__global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int KT = 64;
+  constexpr int SUB = (HD + 63) / 64;                 // 128-byte sub-rows per key row
+  constexpr int TILE = SUB * KT * 128;                // one K (or V) tile
+  constexpr int STAGE = 2 * TILE;                     // K then V
+  constexpr int NKS = HD / 32, NDT = HD / 16;
+  constexpr int PIECES = 2 * SUB * 8;                 // 1-KiB DMA pieces per stage (K: SUB*8, V: SUB*8)
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
+  const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
+
+  Frag<T> qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+  // retire the Q loads before the first DMA (an ordinary load pending beside LDS-DMA makes hipcc drain the whole queue at its first use)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].v));
+
+  // DMA plan: piece i of a stage = 8 rows of one sub-tile; pieces are dealt round-robin over the waves (PIECES / nw or one more each; the
+  // counted wait uses the per-wave count).  lane -> (row, chunk position); it fetches the chunk whose swizzled position is its own.
+  const int r_in = lane >> 3, pch = lane & 7;
+  const int my_pieces = (PIECES - wave + nw - 1) / nw;                 // pieces i = wave, wave + nw, ...
+  auto stage = [&](const int buf, const int tile) {
+    const int key0 = tile * KT;
+    for (int i = wave; i < PIECES; i += nw) {
+      const bool isv = i >= SUB * 8;
+      const int j = isv ? i - SUB * 8 : i;
+      const int sub = j >> 3, r = (j & 7) * 8 + r_in;
+      const int c = pch ^ ((r >> 1) & 7);
+      const int key = min(key0 + r, p.Nk - 1);
+      const T* src = (isv ? V + (long)key * p.v_rs : K + (long)key * p.k_rs) + sub * 64 + c * 8;
+      __builtin_amdgcn_global_load_lds((glb_void_a*)src, (lds_void_a*)(smem + buf * STAGE + (isv ? TILE : 0) + sub * (KT * 128) + (j & 7) * 1024), 16, 0, 0);
+    }
+  };
+
+  float4_t o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float cscale = p.scale * 1.4426950408889634f;
+  const int ntiles = (p.Nk + KT - 1) / KT;
+
+  stage(0, 0);
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int cur = tile & 1;
+    const int key0 = tile * KT;
+    const bool more = tile + 1 < ntiles;
+    if (more) stage(cur ^ 1, tile + 1);
+    // this wave's pieces of the current tile have landed once at most the just-issued ones are outstanding (my_pieces is 1..4)
+    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    const char* Ks = smem + cur * STAGE;
+    const char* Vs = Ks + TILE;
+
+    float4_t sacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int d0 = ks * 32 + g * 8;
+        Frag<T> kf;
+        lds_frag(kf, Ks + (d0 / 64) * (KT * 128), kt * 16 + l15, (d0 % 64) / 8);
+        mma16(sacc[kt], kf, qf[ks]);
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
+    if (key0 + KT > p.Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key0 + kt * 16 + g * 4 + r >= p.Nk) sv[kt * 4 + r] = -INFINITY;
+    }
+    float mx = sv[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    if (__any(m_new != m_run)) {
+      const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+      m_run = m_new;
+    }
+    const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+    l_run += psum;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pj[j] = sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)];
+      Frag<T> pf;
+      PackP<T>::pack(pf, pj);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        // lane i of group g addresses key (kb*32 [+16] + g*4 + i/4), d columns dt*16 + (i%4)*4 .. +3 of the row-major V tile and receives
+        // the 4 keys kb*32 [+16] + g*4 .. +3 of column dt*16 + i
+        const int dcol = dt * 16 + (l15 & 3) * 4;
+        const int sub = dcol >> 6, ch = (dcol & 63) >> 3, half8 = (dcol & 7) * 2;
+        Frag<T> vf;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int key = kb * 32 + hh * 16 + g * 4 + (l15 >> 2);
+          const char* a = Vs + sub * (KT * 128) + key * 128 + ((ch ^ ((key >> 1) & 7)) * 16) + half8;
+          const short4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a);
+          vf.v[hh * 4 + 0] = t[0]; vf.v[hh * 4 + 1] = t[1]; vf.v[hh * 4 + 2] = t[2]; vf.v[hh * 4 + 3] = t[3];
+        }
+        mma16(o[dt], vf, pf);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();          // everybody is done with stage `cur` before the next iteration restages it
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (q < p.Nq) {
+    T* O = reinterpret_cast<T*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      T ov[4] = {Elem<T>::from_f(o[dt][0] * inv), Elem<T>::from_f(o[dt][1] * inv), Elem<T>::from_f(o[dt][2] * inv), Elem<T>::from_f(o[dt][3] * inv)};
+      *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = *reinterpret_cast<const uint2*>(ov);
+    }
+  }
+}
+
 }  // namespace
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
@@ -229,6 +401,14 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   const int rows = nw * 16;
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
   if (p.hd != 0 && p.hd != 64 && p.hd != 96) return VT_ERR_UNSUPPORTED;
+  // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
+  static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 1; }();
+  if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
+    const bool hd96 = p.hd == 96;
+    if (p.dtype == VT_BF16) { if (hd96) hipLaunchKernelGGL((attn16_kernel<bf16_t, 96>), grid, dim3(64 * nw), 0, s, p); else hipLaunchKernelGGL((attn16_kernel<bf16_t, 64>), grid, dim3(64 * nw), 0, s, p); }
+    else { if (hd96) hipLaunchKernelGGL((attn16_kernel<half_t, 96>), grid, dim3(64 * nw), 0, s, p); else hipLaunchKernelGGL((attn16_kernel<half_t, 64>), grid, dim3(64 * nw), 0, s, p); }
+    return vt_check_launch();
+  }
   if (p.hd == 96) {
     if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 96>), grid, dim3(64 * nw), 0, s, p);
     else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t, 96>), grid, dim3(64 * nw), 0, s, p);

@@ -467,6 +467,9 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 
 }  // namespace
 
+static int g_vt_attn_fixed = 1;        // VLATOUCH_ATTN_FIXEDMAX / vt_tune(6, .): fixed-maximum softmax where a score bound is known
+void vt_attn_kvt_tune(int value) { g_vt_attn_fixed = value != 0; }
+
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || (long)p.T * 64 < (long)p.B * p.Nk || p.q_rs % 8) return VT_ERR_ARG;
   int nw = 4, best = 1 << 30;
@@ -481,8 +484,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   // VLATOUCH_ATTN_RING: 0 = the 2-stage whole-tile kernel, 4 / 5 = half-tile ring with counted waits (default 5)
   static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
   // fixed-maximum softmax (see attn_kvt_ring_kernel): only with a finite load-time bound small enough that exp(-2B) stays a normal number
-  static const int fixed_on = [] { const char* e = getenv("VLATOUCH_ATTN_FIXEDMAX"); return e ? atoi(e) : 1; }();
-  const bool fixed = fixed_on && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= 40.f;
+  static const bool init = [] { const char* e = getenv("VLATOUCH_ATTN_FIXEDMAX"); if (e) g_vt_attn_fixed = atoi(e); return true; }();
+  (void)init;
+  const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= 40.f;
 #define VT_KVT_GO(grid) \
   do { if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), 0, s, p); \
        else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false>), grid, dim3(64 * nw), 0, s, p); \

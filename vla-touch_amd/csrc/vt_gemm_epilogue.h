@@ -15,9 +15,11 @@ constexpr int EPT_LD = 36;                     // transposed patch (cmap 2): 64 
 constexpr int EP_BYTES = 64 * EPT_LD * 4;      // per-wave patch: max(32 x EP_LD, 64 x EPT_LD) floats
 
 // one row segment of the read-back: 4 consecutive columns n..n+3 of row m, raw accumulator values in x
+// rpre: the residual values of this segment when the caller loaded them ahead of time (fp32 output only; then Rg must be null)
 template <typename TC, int CMAP, bool ACT>
 __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, const float4 b4, const float4 cs4, const float* hw, const float4 hw4,
-                                               TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok) {   // CMAP here is 0 or 1
+                                               TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok,
+                                               const float4* rpre = nullptr) {   // CMAP here is 0 or 1
   float o[4] = {x.x + b4.x, x.y + b4.y, x.z + b4.z, x.w + b4.w};
   if (hw) {   // per-head RMSNorm over the row's 64 columns = the 16 lanes sharing lane>>4 (wave-uniform branch; all lanes shuffle)
     float q = o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3];
@@ -43,7 +45,8 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
     *reinterpret_cast<uint2*>(Cg + (((long)(ncol0 >> 6) * p.cmap_T + (m >> 6)) * 2) * 4096 + (m & 63) * 64 + (n - ncol0)) =
         *reinterpret_cast<const uint2*>(ov);
   } else if constexpr (sizeof(TC) == 4) {
-    if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
+    if (rpre) { o[0] += rpre->x; o[1] += rpre->y; o[2] += rpre->z; o[3] += rpre->w; }
+    else if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
     *reinterpret_cast<float4*>(Cg + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
   } else {
     if (Rg) {

@@ -28,6 +28,7 @@
 #include "vt_gemm_epilogue.h"
 #include "vt_prof.h"
 #include "vt_host.h"
+#include "vt_kernels.h"
 #include "../../include/vlatouch.h"
 
 extern int g_vt_gm;
@@ -189,8 +190,30 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   for (; t + NB < nk; t += NB) static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::false_type{}); });
   static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::true_type{}); });
 
-  // ---------------- epilogue: accumulators -> the block's fp32 tile in LDS [160][128], 16-byte columns XOR-swizzled by the row
+  // ---------------- epilogue: accumulators -> the block's fp32 tile in LDS [160][128], 16-byte columns XOR-swizzled by the row; read back as
+  // row segments: 16 lanes cover 64 columns (= one head) of one row, 4 rows per instruction; wave w takes column half w & 1 of rows (w >> 1) * 80 ..
   float* tile = reinterpret_cast<float*>(smem);
+  const int half = wave & 1, c4 = lane & 15;
+  const int ncol0 = n0 + half * 64, n = ncol0 + c4 * 4;
+  const bool col_ok = n < p.N;
+  const int rbase = (wave >> 1) * (BM / 2) + (lane >> 4);
+  TC* Cg = reinterpret_cast<TC*>(p.C) + (long)grp * p.c_gs;
+  const TC* Rg = p.residual ? reinterpret_cast<const TC*>(p.residual) + (long)grp * p.r_gs : nullptr;
+  // fp32 residual stream (proj / cross proj / fc2 of an RDT block): the lane's 20 residual segments do not depend on the product, so they are
+  // requested BEFORE the accumulators go through LDS and land behind that exchange (loaded inside the read-back loop they were 20
+  // dependent HBM round trips: the fp32 + residual variant ran 7 us behind the bf16 one)
+  constexpr bool PRE = sizeof(TC) == 4;
+  float4 rpre[PRE ? BM / 8 : 1];
+  const bool use_pre = PRE && Rg != nullptr;
+  if constexpr (PRE) {
+    if (use_pre) {
+#pragma unroll
+      for (int it = 0; it < BM / 8; ++it) {
+        const int m = min(m0 + rbase + it * 4, p.M - 1);
+        rpre[it] = col_ok ? *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Rg) + (long)m * p.ldr + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TMW; ++j) {
     const int m = j * 32 + l31;
@@ -201,27 +224,27 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
     }
   }
   __syncthreads();
-  // read back: 16 lanes cover 64 columns (= one head) of one row, 4 rows per instruction; wave w takes column half w & 1 of rows (w >> 1) * 80 ..
-  const int half = wave & 1, c4 = lane & 15;
-  const int ncol0 = n0 + half * 64, n = ncol0 + c4 * 4;
-  const bool col_ok = n < p.N;
   const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
   const float* hw = nullptr;
   if (p.hn_w0 && ncol0 < p.hn_c0_end) hw = p.hn_w0;
   else if (p.hn_w1 && ncol0 >= p.hn_c0_end && ncol0 < p.hn_c1_end) hw = p.hn_w1;
-  TC* Cg = reinterpret_cast<TC*>(p.C) + (long)grp * p.c_gs;
-  const TC* Rg = p.residual ? reinterpret_cast<const TC*>(p.residual) + (long)grp * p.r_gs : nullptr;
   const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
   const float4 b4 = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : zero4;
   const float4 cs4 = (p.colscale && col_ok) ? *reinterpret_cast<const float4*>(p.colscale + n) : one4;
   const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
-  const int rbase = (wave >> 1) * (BM / 2) + (lane >> 4);
   if (p.act != VT_ACT_NONE) {
 #pragma unroll 2
     for (int it = 0; it < BM / 8; ++it) {
       const int row = rbase + it * 4;
       const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
       vt_epi_segment<TC, 0, true>(p, x, b4, cs4, hw, hw4, Cg, Rg, m0 + row, n, ncol0, col_ok);
+    }
+  } else if (use_pre) {
+#pragma unroll
+    for (int it = 0; it < BM / 8; ++it) {
+      const int row = rbase + it * 4;
+      const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
+      vt_epi_segment<TC, 0, false>(p, x, b4, cs4, hw, hw4, Cg, nullptr, m0 + row, n, ncol0, col_ok, &rpre[PRE ? it : 0]);
     }
   } else {
 #pragma unroll 4
@@ -291,6 +314,7 @@ extern "C" int vt_tune(int knob, int value) {
   if (knob == 1 && (value == 0 || value == 4 || value == 8)) { g_vt_pw_nb = value; return VT_OK; }
   if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
   if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
+  if (knob == 6) { vt_attn_kvt_tune(value); return VT_OK; }
   if (knob == 3 || knob == 4) { vt_gemm_pws_tune(knob, value); return VT_OK; }
   return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
 }

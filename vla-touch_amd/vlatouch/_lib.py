@@ -122,6 +122,7 @@ SIGNATURES = {
     "vt_gemm": (_I, [_P, _P]),
     "vt_randn": (_I, [_P, _L, _P, _I, _P]),
     "vt_slice_cast": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P]),
+    "vt_cast": (_I, [_P, _I, _L, _P, _I, _L, _I, _I, _P]),
     "vt_pack_w32": (_I, [_P, _L, _P, _I, _I, _P]),
     "vt_tune": (_I, [_I, _I]),
     "vt_attention": (_I, [_P, _P]),

@@ -80,6 +80,17 @@ def slice_cast(x: torch.Tensor, T: int, D: int, out: Optional[torch.Tensor] = No
     return out
 
 
+def cast(x: torch.Tensor, dtype: torch.dtype, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x.to(dtype) through vt_cast (one library kernel, no torch kernel): x contiguous, any shape."""
+    assert x.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    L.check(L.lib().vt_cast(L.ptr(x), L.dt_code(x.dtype), cols, L.ptr(out), L.dt_code(dtype), cols, rows, cols, L.stream_ptr(x.device)), "vt_cast")
+    return out
+
+
 def pack_w32(w: torch.Tensor) -> torch.Tensor:
     """w [N, K] 16-bit (N % 32 == 0, K % 16 == 0) -> its copy in MFMA fragment order (vt_pack_w32)."""
     assert w.dim() == 2 and w.stride(1) == 1 and w.element_size() == 2
