@@ -62,68 +62,6 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
   }
 }
 
-// ---- 16-bit outputs, 8 columns per lane: the read-back of a 32 x 64 patch is 4 wave instructions of 8 rows (8 lanes x 8 columns cover a
-// row's 64 columns) and every lane stores 16 bytes.  With 4 columns per lane the epilogue of a 256 x 256 tile was 256 dwordx2 store
-// instructions per CU, and those are issue-bound (~7 B/clk/CU whatever their width, MI355X_MICROARCH.md "epilogue store tail"): the 128 KB of
-// a bf16 tile took ~8 us of a 58 us tile.  Same arithmetic as vt_epi_segment, same order (the head-norm sum runs over 8 lanes of 8 squares).
-__device__ __forceinline__ float row8_sum(float v) {
-  auto dpp = [](float x, auto ctrl) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
-  };
-  v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
-  v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
-  v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror: quad 0 <-> quad 1 of each group of 8
-  return v;
-}
-struct VtEpi8Consts { float4 b[2], cs[2], hw[2]; };
-template <typename TC, int CMAP, bool ACT>
-__device__ __forceinline__ void vt_epi_segment8(const VtGemmParams& p, const float4 x0, const float4 x1, const VtEpi8Consts& k, const float* hw,
-                                                TC* Cg, const TC* Rg, const int m, const int n, const int ncol0, const bool col_ok) {   // CMAP 0 or 1
-  static_assert(sizeof(TC) == 2, "16-bit outputs");
-  float o[8] = {x0.x + k.b[0].x, x0.y + k.b[0].y, x0.z + k.b[0].z, x0.w + k.b[0].w, x1.x + k.b[1].x, x1.y + k.b[1].y, x1.z + k.b[1].z, x1.w + k.b[1].w};
-  if (hw) {
-    float q = 0.f;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) q += o[r] * o[r];
-    q = row8_sum(q);
-    float var;
-    if (p.hn_mode == 2) {
-      float sm = 0.f;
-#pragma unroll
-      for (int r = 0; r < 8; ++r) sm += o[r];
-      const float mean = row8_sum(sm) * (1.f / 64.f);
-      var = (q - 64.f * mean * mean) * (1.f / 63.f);
-    } else var = q * (1.f / 64.f);
-    const float rstd = rsqrtf(var + p.hn_eps);
-    const float g8[8] = {k.hw[0].x, k.hw[0].y, k.hw[0].z, k.hw[0].w, k.hw[1].x, k.hw[1].y, k.hw[1].z, k.hw[1].w};
-#pragma unroll
-    for (int r = 0; r < 8; ++r) o[r] *= rstd * g8[r];
-  }
-  if constexpr (ACT) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) o[r] = act_apply(o[r], p.act);
-  }
-  const float c8[8] = {k.cs[0].x, k.cs[0].y, k.cs[0].z, k.cs[0].w, k.cs[1].x, k.cs[1].y, k.cs[1].z, k.cs[1].w};
-#pragma unroll
-  for (int r = 0; r < 8; ++r) o[r] *= c8[r];
-  if (m >= p.M || !col_ok) return;
-  TC* dst;
-  if constexpr (CMAP == 1) dst = Cg + (((long)(ncol0 >> 6) * p.cmap_T + (m >> 6)) * 2) * 4096 + (m & 63) * 64 + (n - ncol0);
-  else {
-    dst = Cg + (long)m * p.ldc + n;
-    if (Rg) {
-      TC rv[8];
-      *reinterpret_cast<uint4*>(rv) = *reinterpret_cast<const uint4*>(Rg + (long)m * p.ldr + n);
-#pragma unroll
-      for (int r = 0; r < 8; ++r) o[r] += Elem<TC>::to_f(rv[r]);
-    }
-  }
-  TC ov[8];
-#pragma unroll
-  for (int r = 0; r < 8; ++r) ov[r] = Elem<TC>::from_f(o[r]);
-  *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(ov);
-}
-
 // hcol0: the column the tile-stream head index is taken from (== ncol0 except for the V half of a fused K|V projection, CMAP 3)
 template <typename TC, int TM, int CMAP>
 __device__ __forceinline__ void vt_gemm_epilogue_impl(const VtGemmParams& p, float4_t (&acc)[4][TM], float* ep, const int grp, const int mrow0,
@@ -162,64 +100,26 @@ __device__ __forceinline__ void vt_gemm_epilogue_impl(const VtGemmParams& p, flo
         }
       }
     if constexpr (sizeof(TC) == 2 && CMAP == 2) {
-      // Vt tiles (bias only).  A lane takes the 4 keys kq .. kq+3 of BOTH 16-row tiles of the patch for one d row: in the tile's k order
-      // (vt_kpos) the groups k .. k+3 and k+16 .. k+19 are neighbours, so the lane stores 16 contiguous bytes; 4 lanes cover the patch's 32
-      // keys of a d row, 16 d rows per instruction.  (A 16-row last patch, or rows past M, fall back to 8-byte / scalar stores.)
+      // Vt tiles (bias only): 8 lanes cover the patch's 32 rows (= 32 keys, half a tile) of one d row as one 64-byte segment,
+      // 8 d rows per instruction; a lane's 4 keys are an aligned group, contiguous in the tile's k order (vt_kpos).
       const long tbase = (long)(hcol0 >> 6) * p.cmap_T;
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int dd = it * 16 + (lane >> 2), kq = (lane & 3) * 4;
-        const float4 x0 = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + kq);
-        const float4 x1 = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + 16 + kq);
+      for (int it = 0; it < 8; ++it) {
+        const int dd = it * 8 + (lane >> 3), kq = (lane & 7) * 4;
+        const float4 x = *reinterpret_cast<const float4*>(ep + dd * EPT_LD + kq);
         const float bv = bias ? bias[ncol0 + dd] : 0.f;
         const int m = mrow0 + jp * 16 + kq;
-        if (m >= p.M) continue;
-        TC* dst = Cg + ((tbase + (m >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(m & 63);
-        TC ov[8] = {Elem<TC>::from_f(x0.x + bv), Elem<TC>::from_f(x0.y + bv), Elem<TC>::from_f(x0.z + bv), Elem<TC>::from_f(x0.w + bv),
-                    Elem<TC>::from_f(x1.x + bv), Elem<TC>::from_f(x1.y + bv), Elem<TC>::from_f(x1.z + bv), Elem<TC>::from_f(x1.w + bv)};
-        if (nrows == 32 && m + 19 < p.M && ((mrow0 + jp * 16) & 31) == 0) *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(ov);
-        else {
-          for (int e = 0; e < 4; ++e) if (m + e < p.M) dst[e] = ov[e];
-          if (nrows == 32) {
-            TC* dst2 = Cg + ((tbase + ((m + 16) >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos((m + 16) & 63);
-            for (int e = 0; e < 4; ++e) if (m + 16 + e < p.M) dst2[e] = ov[4 + e];
-          }
+        if (m < p.M && kq < nrows) {
+          TC* dst = Cg + ((tbase + (m >> 6)) * 2 + 1) * 4096 + dd * 64 + vt_kpos(m & 63);
+          TC ov[4] = {Elem<TC>::from_f(x.x + bv), Elem<TC>::from_f(x.y + bv), Elem<TC>::from_f(x.z + bv), Elem<TC>::from_f(x.w + bv)};
+          if (m + 3 < p.M) *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(ov);
+          else
+            for (int e = 0; e < 4; ++e) if (m + e < p.M) dst[e] = ov[e];
         }
       }
     } else {
-      bool wide = false;
-      if constexpr (sizeof(TC) == 2) wide = (p.N % 8) == 0 && (CMAP == 1 || ((p.ldc % 8) == 0 && (!Rg || (p.ldr % 8) == 0)));
-      if (wide) {
-        if constexpr (sizeof(TC) == 2) {
-          // 8 lanes cover one row (8 columns each), 8 rows per instruction, 16-byte stores (see vt_epi_segment8)
-          const int c8 = lane & 7, n8 = ncol0 + c8 * 8;
-          const bool ok8 = n8 < p.N;
-          VtEpi8Consts k;
-#pragma unroll
-          for (int hf = 0; hf < 2; ++hf) {
-            k.b[hf] = (bias && ok8) ? *reinterpret_cast<const float4*>(bias + n8 + hf * 4) : zero4;
-            k.cs[hf] = (p.colscale && ok8) ? *reinterpret_cast<const float4*>(p.colscale + n8 + hf * 4) : one4;
-            k.hw[hf] = hw ? *reinterpret_cast<const float4*>(hw + c8 * 8 + hf * 4) : one4;
-          }
-          if (p.act != VT_ACT_NONE) {
-#pragma unroll 2
-            for (int it = 0; it < nrows / 8; ++it) {
-              const int row = it * 8 + (lane >> 3);
-              const float4 x0 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 * 8), x1 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 * 8 + 4);
-              vt_epi_segment8<TC, CMAP, true>(p, x0, x1, k, hw, Cg, Rg, mrow0 + jp * 16 + row, n8, ncol0, ok8);
-            }
-          } else {
-#pragma unroll
-            for (int it = 0; it < 4; ++it) {
-              if (it * 8 >= nrows) break;
-              const int row = it * 8 + (lane >> 3);
-              const float4 x0 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 * 8), x1 = *reinterpret_cast<const float4*>(ep + row * EP_LD + c8 * 8 + 4);
-              vt_epi_segment8<TC, CMAP, false>(p, x0, x1, k, hw, Cg, Rg, mrow0 + jp * 16 + row, n8, ncol0, ok8);
-            }
-          }
-        }
-      } else if (p.act != VT_ACT_NONE) {
-        // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
+      // read the 32 x 64 patch back row-contiguously: 16 lanes cover one row (64 floats), 4 rows per instruction
+      if (p.act != VT_ACT_NONE) {
 #pragma unroll 2
         for (int it = 0; it < nrows / 4; ++it) {
           const int row = it * 4 + (lane >> 4);

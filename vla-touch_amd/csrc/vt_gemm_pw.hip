@@ -232,35 +232,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   const float4 b4 = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : zero4;
   const float4 cs4 = (p.colscale && col_ok) ? *reinterpret_cast<const float4*>(p.colscale + n) : one4;
   const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
-  bool wide = false;
-  if constexpr (sizeof(TC) == 2) wide = (p.ldc % 8) == 0 && (!Rg || (p.ldr % 8) == 0);
-  if (wide) {
-    if constexpr (sizeof(TC) == 2) {
-      // 16-bit outputs: 8 lanes x 8 columns cover the row's 64-column half, 8 rows per instruction, 16-byte stores (vt_epi_segment8)
-      const int c8 = lane & 7, n8 = ncol0 + c8 * 8;
-      VtEpi8Consts k;
-#pragma unroll
-      for (int hf = 0; hf < 2; ++hf) {
-        k.b[hf] = bias ? *reinterpret_cast<const float4*>(bias + n8 + hf * 4) : zero4;
-        k.cs[hf] = p.colscale ? *reinterpret_cast<const float4*>(p.colscale + n8 + hf * 4) : one4;
-        k.hw[hf] = hw ? *reinterpret_cast<const float4*>(hw + c8 * 8 + hf * 4) : one4;
-      }
-      const int rb8 = (wave >> 1) * (BM / 2) + (lane >> 3);
-      auto seg = [&](const int it, auto actc) {
-        const int row = rb8 + it * 8;
-        const float4 x0 = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c8 * 2) ^ (row & 7)) * 4));
-        const float4 x1 = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c8 * 2 + 1) ^ (row & 7)) * 4));
-        vt_epi_segment8<TC, 0, decltype(actc)::value>(p, x0, x1, k, hw, Cg, Rg, m0 + row, n8, ncol0, true);
-      };
-      if (p.act != VT_ACT_NONE) {
-#pragma unroll 2
-        for (int it = 0; it < BM / 16; ++it) seg(it, std::true_type{});
-      } else {
-#pragma unroll
-        for (int it = 0; it < BM / 16; ++it) seg(it, std::false_type{});
-      }
-    }
-  } else if (p.act != VT_ACT_NONE) {
+  if (p.act != VT_ACT_NONE) {
 #pragma unroll 2
     for (int it = 0; it < BM / 8; ++it) {
       const int row = rbase + it * 4;
