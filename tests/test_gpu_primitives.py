@@ -147,7 +147,8 @@ def test_groupnorm_mish_film_residual(dev, T, Cc):
     assert rel_err(ops.groupnorm_cl(slabs, bias, gamma, beta, B=B, T=T, residual=res), ref2) < 2e-5
 
 
-@pytest.mark.parametrize("D,rows", [(256, 37), (384, 37), (768, 37), (2048, 37), (2048, 300), (1152, 261)])
+# rows >= 8192: the wave-per-row kernel of the ViT towers (SigLIP 1152-wide, DINOv2 768-wide rows)
+@pytest.mark.parametrize("D,rows", [(256, 37), (384, 37), (768, 37), (2048, 37), (2048, 300), (1152, 261), (1152, 9001), (768, 8200), (2048, 8193)])
 def test_rownorm_modes(dev, D, rows):
     from vlatouch import ops, _lib as L
     x, w, b = rnd((rows, D), 1, dev), rnd((D,), 2, dev) + 1, rnd((D,), 3, dev)

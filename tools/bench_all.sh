@@ -19,3 +19,5 @@ run siglip_n1 --workload siglip --no-cpu-baseline --steps 6 --warmup 1
 run lstm_n1 --workload lstm --no-cpu-baseline
 run marker_n1 --workload marker --no-cpu-baseline
 run full_b1_n1 --batch 1 --streams 1 --no-cpu-baseline
+run robot_n1 --workload robot --no-cpu-baseline --steps 6 --warmup 1
+run robot_b1_n1 --workload robot --batch 1 --streams 1 --no-cpu-baseline --steps 10 --warmup 2

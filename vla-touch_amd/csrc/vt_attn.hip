@@ -267,8 +267,9 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
       const bool isv = i >= SUB * 8;
       const int j = isv ? i - SUB * 8 : i;
       const int sub = j >> 3, r = (j & 7) * 8 + r_in;
-      const int c = pch ^ ((r >> 1) & 7);
-      const int key = min(key0 + r, p.Nk - 1);
+      int c = pch ^ ((r >> 1) & 7);
+      if (HD % 64 != 0 && sub == SUB - 1 && c >= (HD % 64) / 8) c &= (HD % 64) / 8 - 1;   // chunks past the head's last column are never used by an
+      const int key = min(key0 + r, p.Nk - 1);                                           // MFMA: fetch an in-bounds chunk instead (no read past the row)
       const T* src = (isv ? V + (long)key * p.v_rs : K + (long)key * p.k_rs) + sub * 64 + c * 8;
       __builtin_amdgcn_global_load_lds((glb_void_a*)src, (lds_void_a*)(smem + buf * STAGE + (isv ? TILE : 0) + sub * (KT * 128) + (j & 7) * 1024), 16, 0, 0);
     }

@@ -3,6 +3,7 @@
 // over split-K partial slabs (one wave per (sample, group), group staged in LDS), per-head q/k RMSNorm,
 // image statistics + patchify (one HBM read of the frames), the SDE update, action (de)normalisation
 // and the small glue kernels of the U-Net / LSTM drivers.
+#include <stdlib.h>
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -118,6 +119,60 @@ __global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c4 = tid + 256 * i;
+    if (c4 < nv) {
+      const float4 ww = *reinterpret_cast<const float4*>(w + c4 * 4);
+      float o[4] = {(v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y, (v[i].z - mean) * rstd * ww.z, (v[i].w - mean) * rstd * ww.w};
+      if (b) { const float4 bb = *reinterpret_cast<const float4*>(b + c4 * 4); o[0] += bb.x; o[1] += bb.y; o[2] += bb.z; o[3] += bb.w; }
+      if constexpr (sizeof(TO) == 4) *reinterpret_cast<float4*>(yr + c4 * 4) = make_float4(o[0], o[1], o[2], o[3]);
+      else {
+        TO t[4] = {Elem<TO>::from_f(o[0]), Elem<TO>::from_f(o[1]), Elem<TO>::from_f(o[2]), Elem<TO>::from_f(o[3])};
+        *reinterpret_cast<uint2*>(yr + c4 * 4) = *reinterpret_cast<const uint2*>(t);
+      }
+    }
+  }
+}
+
+// many wide rows (the ViT towers: 139 968 x 1152 for the SigLIP step, 16 448 x 768 for DINOv2): one WAVE per row, 4 rows per block, 16-byte
+// loads held in registers, reductions by wave shuffles only — no LDS, no block barrier (the block-per-row kernel above pays two to four
+// __syncthreads() per row and keeps a quarter of the bytes in flight per CU; it stays for the few-row RMSNorms of the RDT step loop)
+template <typename TO, int NV>
+__global__ __launch_bounds__(256) void rownorm_wave_kernel(const float* __restrict__ x, long ldx, TO* __restrict__ y, long ldy, const float* __restrict__ w,
+                                                           const float* __restrict__ b, int rows, int D, float eps, int mode) {
+  const int lane = threadIdx.x & 63;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + row * ldx;
+  const int nv = D >> 2;
+  float4 v[NV];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
+    v[i] = c4 < nv ? *reinterpret_cast<const float4*>(xr + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    q += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+  }
+  float mean = 0.f, var;
+  if (mode == VT_NORM_RMS_MEANSQ) {
+    var = wave_sum(q) / (float)D;
+  } else {
+    mean = wave_sum(s) / (float)D;
+    float d2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+      if (lane + 64 * i < nv) {
+        const float a0 = v[i].x - mean, a1 = v[i].y - mean, a2 = v[i].z - mean, a3 = v[i].w - mean;
+        d2 += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    d2 = wave_sum(d2);
+    var = (mode == VT_NORM_RMS_VAR) ? d2 / (float)(D - 1) : d2 / (float)D;
+    if (mode == VT_NORM_RMS_VAR) mean = 0.f;
+  }
+  const float rstd = rsqrtf(var + eps);
+  TO* yr = y + row * ldy;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c4 = lane + 64 * i;
     if (c4 < nv) {
       const float4 ww = *reinterpret_cast<const float4*>(w + c4 * 4);
       float o[4] = {(v[i].x - mean) * rstd * ww.x, (v[i].y - mean) * rstd * ww.y, (v[i].z - mean) * rstd * ww.z, (v[i].w - mean) * rstd * ww.w};
@@ -524,6 +579,16 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
                  float eps, int mode, hipStream_t s) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
+  static const int wave_rows = [] { const char* e = getenv("VLATOUCH_ROWNORM_WAVE"); return e ? atoi(e) : 8192; }();   // rows from which the wave-per-row kernel takes over (0 = never)
+  if (xdt == VT_F32 && D >= 512 && wave_rows > 0 && rows >= wave_rows && (ldx % 4) == 0 && (ldy % 4) == 0) {
+    const dim3 grid((unsigned)((rows + 3) / 4));
+#define VT_RNW(TO, NV) hipLaunchKernelGGL((rownorm_wave_kernel<TO, NV>), grid, dim3(256), 0, s, (const float*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode)
+#define VT_RNW_T(TO) do { if (D <= 1024) VT_RNW(TO, 4); else if (D <= 1280) VT_RNW(TO, 5); else VT_RNW(TO, 8); } while (0)
+    if (ydt == VT_F32) VT_RNW_T(float); else if (ydt == VT_F16) VT_RNW_T(half_t); else VT_RNW_T(bf16_t);
+#undef VT_RNW_T
+#undef VT_RNW
+    return vt_check_launch();
+  }
   if (xdt == VT_F32 && D >= 512 && (rows >= 256 || D >= 1024) && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row (also for few wide rows: latency)
     if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
     else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode);
