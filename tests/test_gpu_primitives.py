@@ -256,6 +256,26 @@ def test_attention_head_dim_96(dev, mode, Nq, Nk):
     assert float(out.float().reshape(B, Nq, H, 96)[..., 72:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("Nq,Nk", [(729, 729), (36, 36), (100, 257), (67, 130)])
+def test_attention_head_dim_80(dev, mode, Nq, Nk):
+    """hd = 80 (SigLIP's 72-wide heads zero-padded to the next multiple of 16 in the 16-bit modes): two 32-deep MFMA steps + one 16-deep step
+    for q.k, five 16-row output tiles; the LAST head's rows end exactly at the tensor's end (the DMA must not read past them)."""
+    from vlatouch import ops
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+    B, H = 2, 3
+    qkv = rnd((B, max(Nq, Nk), 3, H, 80), 7, dev, dt)
+    qkv[..., 72:] = 0
+    q, k, v = qkv[:, :Nq, 0], qkv[:, :Nk, 1], qkv[:, :Nk, 2]
+    out = ops.attention(q, k, v, scale=72 ** -0.5)
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * 72 ** -0.5
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, Nq, H * 80)
+    assert rel_err(out.float(), ref) < {"bf16": 1.5e-2, "f16": 2e-3}[mode]
+    assert float(out.float().reshape(B, Nq, H, 80)[..., 72:].abs().max()) == 0.0
+    with pytest.raises(Exception):
+        ops.attention(q.float(), k.float(), v.float(), scale=72 ** -0.5)          # fp32 keeps 96-wide padding
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(70, 100, 64, 1), (33, 64, 96, 1), (200, 260, 1056, 1), (512, 512, 2560, 3), (64, 1280, 2048, 8), (257, 36, 160, 2)])
 def test_fp32_ring_gemm_edges(dev, M, N, K, splitk):
     """vt_gemm_f32r.hip (bias-only exact-fp32 products with few blocks per CU): ragged M / N (clamped rows, scalar stores when N % 4 != 0),

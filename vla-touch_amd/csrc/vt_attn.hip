@@ -222,22 +222,42 @@ __global__ __launch_bounds__(512) void attn_kernel(const VtAttnParams p) {
 //     more LDS instructions than everything else in the tile;
 //   * the Vt fragment (4 consecutive keys of one d column) is read from the row-major V tile with ds_read_b64_tr_b16: the 16 lanes of a lane
 //     group address a [4 keys][16 d] block (lane i: key i/4, d columns (i%4)*4 .. +3) and the hardware hands lane i the 4 keys of column i;
-//   * two LDS stages: the DMA of tile t+1 is issued before the MFMAs of tile t, waits are counted (vmcnt) and the barriers raw.
+//   * a ring of three LDS stages: two tiles are in flight behind the one being consumed, waits are counted (vmcnt), ONE raw barrier per tile.
 // No key mask here (masked calls keep attn_kernel).  Keys past Nk in the last tile are clamped loads, masked in the softmax.
 typedef __attribute__((address_space(3))) void lds_void_a;
 typedef const __attribute__((address_space(1))) void glb_void_a;
 typedef __attribute__((ext_vector_type(4))) short short4_t;
 
+// 16-deep tail step of a head dimension that is not a multiple of 32 (SigLIP's 72-wide heads run padded to 80 = 2 x 32 + 16): v_mfma_f32_16x16x16,
+// a lane (row l15, group g) holds the 4 elements k = g*4 .. g*4+3 of both operands
+typedef __attribute__((ext_vector_type(4))) _Float16 half4v_t;
+template <typename T> __device__ __forceinline__ void mma16_k16(float4_t& acc, const short4_t a, const short4_t b);
+template <> __device__ __forceinline__ void mma16_k16<bf16_t>(float4_t& acc, const short4_t a, const short4_t b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, acc, 0, 0, 0);
+}
+template <> __device__ __forceinline__ void mma16_k16<half_t>(float4_t& acc, const short4_t a, const short4_t b) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4v_t, a), __builtin_bit_cast(half4v_t, b), acc, 0, 0, 0);
+}
+
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   static_assert(sizeof(T) == 2, "16-bit types only");
   constexpr int KT = 64;
-  constexpr int SUB = (HD + 63) / 64;                 // 128-byte sub-rows per key row
-  constexpr int TILE = SUB * KT * 128;                // one K (or V) tile
-  constexpr int STAGE = 2 * TILE;                     // K then V
   constexpr int NKS = HD / 32, NDT = HD / 16;
-  constexpr int PIECES = 2 * SUB * 8;                 // 1-KiB DMA pieces per stage (K: SUB*8, V: SUB*8)
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  constexpr bool TAIL16 = (HD % 32) == 16;            // one 16-deep step behind the NKS 32-deep ones
+  static_assert(HD >= 64 && HD <= 128 && HD % 16 == 0 && (HD % 32 == 0 || HD % 32 == 16), "head dimension: 64 .. 128, multiple of 16");
+  // LDS image of a K (or V) tile: MAIN = [64 keys][128 B] for d 0..63 (16-byte chunks XOR-swizzled by the row) followed by a compact TAIL =
+  // [64 keys][TW bytes] for d 64.. (linear: its reads are contiguous as they are) — 8 / 10 / 12 KiB for 64 / 80 / 96-wide heads, so THREE stages
+  // (K + V each) still leave two blocks per CU
+  constexpr int TW = (HD - 64) * 2;                   // tail bytes per key row: 0, 32, 64
+  constexpr int MAINB = KT * 128;
+  constexpr int TILE = MAINB + KT * TW;
+  constexpr int STAGE = 2 * TILE;                     // K then V
+  constexpr int NST = 3;
+  constexpr int TP = KT * TW / 1024;                  // tail DMA pieces per tile (a piece = 1 KiB = 1024 / TW rows)
+  constexpr int PT = 8 + TP;                          // pieces per tile
+  constexpr int PIECES = 2 * PT;                      // per stage
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -252,27 +272,47 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   Frag<T> qf[NKS];
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+  short4_t q16 = {0, 0, 0, 0};
+  if constexpr (TAIL16) { if (q < p.Nq) q16 = *reinterpret_cast<const short4_t*>(Q + (long)q * p.q_rs + NKS * 32 + g * 4); }
   // retire the Q loads before the first DMA (an ordinary load pending beside LDS-DMA makes hipcc drain the whole queue at its first use)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].v));
+  asm volatile("" : "+v"(q16));
 
-  // DMA plan: piece i of a stage = 8 rows of one sub-tile; pieces are dealt round-robin over the waves (PIECES / nw or one more each; the
-  // counted wait uses the per-wave count).  lane -> (row, chunk position); it fetches the chunk whose swizzled position is its own.
-  const int r_in = lane >> 3, pch = lane & 7;
+  // DMA plan: the PIECES 1-KiB pieces of a stage are dealt round-robin over the waves (the counted wait uses the per-wave count).  Main
+  // pieces: 8 rows x 128 B, lane -> (row, chunk position), it fetches the chunk whose swizzled position is its own; tail pieces: 1024 / TW
+  // rows x TW bytes, linear.
   const int my_pieces = (PIECES - wave + nw - 1) / nw;                 // pieces i = wave, wave + nw, ...
-  auto stage = [&](const int buf, const int tile) {
+  auto stage = [&](const int slot, const int tile) {
     const int key0 = tile * KT;
     for (int i = wave; i < PIECES; i += nw) {
-      const bool isv = i >= SUB * 8;
-      const int j = isv ? i - SUB * 8 : i;
-      const int sub = j >> 3, r = (j & 7) * 8 + r_in;
-      int c = pch ^ ((r >> 1) & 7);
-      if (HD % 64 != 0 && sub == SUB - 1 && c >= (HD % 64) / 8) c &= (HD % 64) / 8 - 1;   // chunks past the head's last column are never used by an
-      const int key = min(key0 + r, p.Nk - 1);                                           // MFMA: fetch an in-bounds chunk instead (no read past the row)
-      const T* src = (isv ? V + (long)key * p.v_rs : K + (long)key * p.k_rs) + sub * 64 + c * 8;
-      __builtin_amdgcn_global_load_lds((glb_void_a*)src, (lds_void_a*)(smem + buf * STAGE + (isv ? TILE : 0) + sub * (KT * 128) + (j & 7) * 1024), 16, 0, 0);
+      const bool isv = i >= PT;
+      const int j = isv ? i - PT : i;
+      const T* base = isv ? V : K;
+      const long rs = isv ? p.v_rs : p.k_rs;
+      char* dst = smem + slot * STAGE + (isv ? TILE : 0);
+      if (TP == 0 || j < 8) {
+        const int r = j * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((r >> 1) & 7);
+        __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + c * 8), (lds_void_a*)(dst + j * 1024), 16, 0, 0);
+      } else if constexpr (TP > 0) {
+        constexpr int CPR = TW / 16;                  // 16-byte chunks per tail row: 2 or 4
+        const int r = (j - 8) * (64 / CPR) + lane / CPR;
+        const int c = lane % CPR;
+        __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + 64 + c * 8), (lds_void_a*)(dst + MAINB + (j - 8) * 1024), 16, 0, 0);
+      }
     }
+  };
+  auto wait_own = [&](const bool younger_in_flight) {   // this wave's pieces of the oldest outstanding stage have landed
+    if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
 
   float4_t o[NDT];
@@ -282,42 +322,48 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   const float cscale = p.scale * 1.4426950408889634f;
   const int ntiles = (p.Nk + KT - 1) / KT;
 
+  // ring of NST = 3 stages, two tiles in flight behind the one being consumed; ONE barrier per tile: it publishes tile t (every wave waited
+  // for its own pieces) and proves that everybody is done with tile t-1, whose slot the DMA of tile t+2 then takes
   stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  int slot = 0;
   for (int tile = 0; tile < ntiles; ++tile) {
-    const int cur = tile & 1;
     const int key0 = tile * KT;
-    const bool more = tile + 1 < ntiles;
-    if (more) stage(cur ^ 1, tile + 1);
-    // this wave's pieces of the current tile have landed once at most the just-issued ones are outstanding (my_pieces is 1..4)
-    if (!more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-    else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_own(tile + 1 < ntiles);
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    const char* Ks = smem + cur * STAGE;
+    if (tile + 2 < ntiles) stage(slot == 0 ? 2 : slot - 1, tile + 2);
+    const char* Ks = smem + slot * STAGE;
     const char* Vs = Ks + TILE;
+    slot = slot == NST - 1 ? 0 : slot + 1;
 
-    float4_t sacc[4];
+    float4_t sacc[4], tacc[4];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      const int row = kt * 16 + l15;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        const int d0 = ks * 32 + g * 8;
         Frag<T> kf;
-        lds_frag(kf, Ks + (d0 / 64) * (KT * 128), kt * 16 + l15, (d0 % 64) / 8);
+        if (ks < 2) lds_frag(kf, Ks, row, ks * 4 + g);                                                  // d 0..63: the swizzled main image
+        else kf.v = *reinterpret_cast<const short8_t*>(Ks + MAINB + row * TW + (ks - 2) * 64 + g * 16);  // d 64..: the linear tail
         mma16(sacc[kt], kf, qf[ks]);
+      }
+      if constexpr (TAIL16) {
+        // into its OWN accumulator, added on the VALU below: chained straight behind the 8-pass 16x16x32 MFMAs on the same accumulator, the
+        // 4-pass 16x16x16 read registers 0..1 of the last key tile before they were written (scores of keys 48 + 4g + {0, 1} lost their d < 64
+        // part; tools/_dbg pinpointed it) — hipcc 7.2 does not pad that SrcC hazard between the two instruction lengths
+        const short4_t k16 = *reinterpret_cast<const short4_t*>(Ks + MAINB + row * TW + (NKS - 2) * 64 + g * 8);
+        tacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        mma16_k16<T>(tacc[kt], k16, q16);
       }
     }
     float sv[16];
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = sacc[kt][r];
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = TAIL16 ? sacc[kt][r] + tacc[kt][r] : sacc[kt][r];
     if (key0 + KT > p.Nk) {
 #pragma unroll
       for (int kt = 0; kt < 4; ++kt)
@@ -357,21 +403,18 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
         // lane i of group g addresses key (kb*32 [+16] + g*4 + i/4), d columns dt*16 + (i%4)*4 .. +3 of the row-major V tile and receives
         // the 4 keys kb*32 [+16] + g*4 .. +3 of column dt*16 + i
         const int dcol = dt * 16 + (l15 & 3) * 4;
-        const int sub = dcol >> 6, ch = (dcol & 63) >> 3, half8 = (dcol & 7) * 2;
         Frag<T> vf;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
           const int key = kb * 32 + hh * 16 + g * 4 + (l15 >> 2);
-          const char* a = Vs + sub * (KT * 128) + key * 128 + ((ch ^ ((key >> 1) & 7)) * 16) + half8;
+          const char* a = dt < 4 ? Vs + key * 128 + (((dcol >> 3) ^ ((key >> 1) & 7)) * 16) + (dcol & 7) * 2
+                                 : Vs + MAINB + key * TW + (dcol - 64) * 2;
           const short4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a);
           vf.v[hh * 4 + 0] = t[0]; vf.v[hh * 4 + 1] = t[1]; vf.v[hh * 4 + 2] = t[2]; vf.v[hh * 4 + 3] = t[3];
         }
         mma16(o[dt], vf, pf);
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();          // everybody is done with stage `cur` before the next iteration restages it
-    __builtin_amdgcn_sched_barrier(0);
   }
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
@@ -401,15 +444,18 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   }
   const int rows = nw * 16;
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
-  if (p.hd != 0 && p.hd != 64 && p.hd != 96) return VT_ERR_UNSUPPORTED;
+  if (p.hd != 0 && p.hd != 64 && p.hd != 96 && p.hd != 80) return VT_ERR_UNSUPPORTED;
   // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
   static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 1; }();
   if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
-    const bool hd96 = p.hd == 96;
-    if (p.dtype == VT_BF16) { if (hd96) hipLaunchKernelGGL((attn16_kernel<bf16_t, 96>), grid, dim3(64 * nw), 0, s, p); else hipLaunchKernelGGL((attn16_kernel<bf16_t, 64>), grid, dim3(64 * nw), 0, s, p); }
-    else { if (hd96) hipLaunchKernelGGL((attn16_kernel<half_t, 96>), grid, dim3(64 * nw), 0, s, p); else hipLaunchKernelGGL((attn16_kernel<half_t, 64>), grid, dim3(64 * nw), 0, s, p); }
+#define VT_A16(T) do { if (p.hd == 96) hipLaunchKernelGGL((attn16_kernel<T, 96>), grid, dim3(64 * nw), 0, s, p); \
+                       else if (p.hd == 80) hipLaunchKernelGGL((attn16_kernel<T, 80>), grid, dim3(64 * nw), 0, s, p); \
+                       else hipLaunchKernelGGL((attn16_kernel<T, 64>), grid, dim3(64 * nw), 0, s, p); } while (0)
+    if (p.dtype == VT_BF16) VT_A16(bf16_t); else VT_A16(half_t);
+#undef VT_A16
     return vt_check_launch();
   }
+  if (p.hd == 80) return VT_ERR_UNSUPPORTED;          // 80-wide (padded 72) heads exist only in the 16-bit DMA-staged kernel
   if (p.hd == 96) {
     if (p.dtype == VT_BF16) hipLaunchKernelGGL((attn_kernel<bf16_t, 96>), grid, dim3(64 * nw), 0, s, p);
     else if (p.dtype == VT_F16) hipLaunchKernelGGL((attn_kernel<half_t, 96>), grid, dim3(64 * nw), 0, s, p);

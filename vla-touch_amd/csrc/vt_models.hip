@@ -45,9 +45,9 @@ int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_din
   if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_dino_create: null argument");
   const vt_dino_desc& d = *desc;
   const int hd = d.head_dim ? d.head_dim : 64;
-  if (d.layers < 1 || d.layers > 48 || d.hidden % 64 || (hd != 64 && hd != 96) || (hd == 64 && d.hidden / d.heads != 64) || d.patch != 14 ||
+  if (d.layers < 1 || d.layers > 48 || d.hidden % 64 || (hd != 64 && hd != 96 && !(hd == 80 && d.adt != VT_F32)) || (hd == 64 && d.hidden / d.heads != 64) || d.patch != 14 ||
       d.kpad % 16 || d.kpad < 588 || (d.mlp_dim % 16))
-    return vt_fail(VT_ERR_ARG, "vt_dino_create: unsupported config (head_dim 64 / 96, patch 14)");
+    return vt_fail(VT_ERR_ARG, "vt_dino_create: unsupported config (head_dim 64 / 96, or 80 in a 16-bit mode; patch 14)");
   if (n != vt_dino_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_dino_create: expected %d weights, got %d", vt_dino_num_weights(desc), n);
   for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_dino_create: weight %d is null", k);
   vt_dino_s* h = new (std::nothrow) vt_dino_s();

@@ -332,7 +332,9 @@ class SiglipEngine:
         hd = D // heads
         if hd * heads != D or hd > self.HD_PAD or D % 64:
             raise L.VtError(f"SiglipEngine: hidden {D} / heads {heads} not supported (head_dim <= 96, hidden % 64 == 0)")
-        HP = self.HD_PAD if hd != 64 else 64
+        # head width on the device: 64 as is; otherwise the next multiple of 16 (16-bit modes: 72 -> 80 = two 32-deep MFMA steps + one 16-deep)
+        # or 96 (fp32 mode, whose attention kernel takes 32-deep steps only); zero padding is exact
+        HP = 64 if hd == 64 else ((hd + 15) // 16 * 16 if (cdt != L.F32 and hd <= 80 and hd > 64) else self.HD_PAD)
         Da = heads * HP
         self.hidden, self.heads, self.patch, self.head_dim = D, heads, patch, hd
         self.kpad = _pad_to(3 * patch * patch, 16 if cdt == L.F32 else 64)

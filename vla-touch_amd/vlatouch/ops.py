@@ -122,10 +122,10 @@ def conv1d_cl(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tens
 
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, scale: Optional[float] = None,
               kmask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """q [B,Nq,H,hd], k/v [B,Nk,H,hd], hd 64 or 96 (any strides with unit inner stride) -> [B,Nq,H*hd].  kmask [B,Nk] bool."""
+    """q [B,Nq,H,hd], k/v [B,Nk,H,hd], hd 64, 96 or (16-bit, unmasked) 80 (any strides with unit inner stride) -> [B,Nq,H*hd].  kmask [B,Nk] bool."""
     B, Nq, H, hd = q.shape
     Nk = k.shape[1]
-    assert hd in (64, 96) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
+    assert hd in (64, 80, 96) and q.stride(3) == 1 and k.stride(3) == 1 and v.stride(3) == 1
     o = torch.empty(B, Nq, H * hd, dtype=q.dtype, device=q.device)
     p = L.AttnParams()
     p.Q, p.K, p.V, p.O = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr()
