@@ -37,7 +37,7 @@ struct Blk {
   // fragment-packed second copies of the per-denoise-step Linears (vt_rdt_set_packed; null = not packed): vt_gemm_pw.hip
   const void *qkv_wp, *proj_wp, *cq_wp, *cproj_wp, *fc1_wp, *fc2_wp;
 };
-struct Adaptor { int n; const void* w[4]; const float* b[4]; int kin; };
+struct Adaptor { int n; const void* w[4]; const float* b[4]; int kin; const void* wp[4]; };
 
 VtGemmParams lin(const void* A, int adt, long lda, const void* W, int cdt, long ldw, const float* b, void* C, int odt, long ldc, int M, int N,
                  int K, int act, const void* Wp = nullptr) {
@@ -58,7 +58,7 @@ struct vt_rdt_s {
   Blk blk[64];
   const float *normf, *ffc1_b, *ffc2_b;
   const void *ffc1_w, *ffc2_w;
-  const void* ffc1_wp;
+  const void *ffc1_wp, *ffc2_wp, *t_w1p, *t_w2p;      // + the small per-step Linears (timestep embedder, final projection; state adaptor: Adaptor::wp)
   float score_bound[64];        // per block: upper bound of |q . k| * scale in its cross-attention (vt_rdt_set_score_bounds), 0 = unknown
   Adaptor lang, img, state;
 };
@@ -110,30 +110,38 @@ int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n) {
 // Fragment-packed second copies of the Linears of the denoise loop (qkv, proj, cross q, cross proj, fc1, fc2 of every block + the final
 // fc1): the caller owns `buf` (vt_rdt_packed_bytes(h) bytes, resident as long as the handle is used); the packing kernels are enqueued
 // on `stream`.  Returns 0 bytes when the configuration has no use for them (fp32 mode, hidden size not a multiple of 512).
+static bool pk_ok(int N, int K) { return N % 64 == 0 && K % 256 == 0; }      // what vt_gemm_pws.hip / vt_gemm_pw.hip can take
 size_t vt_rdt_packed_bytes(vt_rdt_t h) {
   if (!h || h->d.cdt != VT_BF16 || h->d.hidden % 512) return 0;
-  const size_t DD = (size_t)h->d.hidden * h->d.hidden * 2;
-  return (size_t)h->d.depth * 8 * DD + DD;
+  const size_t D = h->d.hidden, DD = D * D * 2;
+  size_t n = (size_t)h->d.depth * 8 * DD + DD;                                // blocks + final fc1
+  if (pk_ok(h->d.out_dim, (int)D)) n += (size_t)h->d.out_dim * D * 2;           // final fc2
+  n += D * 256 * 2 + DD;                                                       // timestep embedder
+  for (int i = 0; i < h->state.n; ++i) { const int K = i == 0 ? h->state.kin : (int)D; if (pk_ok((int)D, K)) n += D * K * 2; }
+  return n;
 }
 int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream) {
   if (!h) return vt_fail(VT_ERR_ARG, "vt_rdt_set_packed: null handle");
   if (!vt_rdt_packed_bytes(h)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_rdt_set_packed: this configuration has no packed weights");
   if (!buf) return vt_fail(VT_ERR_ARG, "vt_rdt_set_packed: null buffer");
   const int D = h->d.hidden;
-  const size_t DD = (size_t)D * D * 2;
   char* o = (char*)buf;
-  auto pk = [&](const void* W, int N, const void** slot) -> int {
-    const int r = vt_pack_w32(W, D, o, N, D, stream);
+  auto pk = [&](const void* W, int N, int K, const void** slot) -> int {
+    if (!pk_ok(N, K)) { *slot = nullptr; return VT_OK; }
+    const int r = vt_pack_w32(W, K, o, N, K, stream);
     if (r) return r;
-    *slot = o; o += (size_t)(N / D) * DD;
+    *slot = o; o += (size_t)N * K * 2;
     return VT_OK;
   };
   for (int l = 0; l < h->d.depth; ++l) {
     Blk& b = h->blk[l];
-    CK(pk(b.qkv_w, 3 * D, &b.qkv_wp)); CK(pk(b.proj_w, D, &b.proj_wp)); CK(pk(b.cq_w, D, &b.cq_wp)); CK(pk(b.cproj_w, D, &b.cproj_wp));
-    CK(pk(b.fc1_w, D, &b.fc1_wp)); CK(pk(b.fc2_w, D, &b.fc2_wp));
+    CK(pk(b.qkv_w, 3 * D, D, &b.qkv_wp)); CK(pk(b.proj_w, D, D, &b.proj_wp)); CK(pk(b.cq_w, D, D, &b.cq_wp)); CK(pk(b.cproj_w, D, D, &b.cproj_wp));
+    CK(pk(b.fc1_w, D, D, &b.fc1_wp)); CK(pk(b.fc2_w, D, D, &b.fc2_wp));
   }
-  CK(pk(h->ffc1_w, D, &h->ffc1_wp));
+  CK(pk(h->ffc1_w, D, D, &h->ffc1_wp));
+  CK(pk(h->ffc2_w, h->d.out_dim, D, &h->ffc2_wp));
+  CK(pk(h->t_w1, D, 256, &h->t_w1p)); CK(pk(h->t_w2, D, D, &h->t_w2p));
+  for (int i = 0; i < h->state.n; ++i) CK(pk(h->state.w[i], D, i == 0 ? h->state.kin : D, &h->state.wp[i]));
   return VT_OK;
 }
 
@@ -243,26 +251,30 @@ int run_adaptor(RCtx& c, const Adaptor& ad, const void* in, long rows_per_sample
     const bool last = i == ad.n - 1;
     void* o = last ? dst : (void*)((i & 1) ? tB : tA);
     // GELU(tanh) sits BEFORE every Linear except the first (rdt_runner.py:97-101): fuse it into the previous epilogue
-    VtGemmParams p = lin(cur, d.adt, ld, ad.w[i], d.cdt, K, ad.b[i], o, d.adt, D, (int)(rows_per_sample * samples), D, K, last ? VT_ACT_NONE : VT_ACT_GELU_TANH);
+    VtGemmParams p = lin(cur, d.adt, ld, ad.w[i], d.cdt, K, ad.b[i], o, d.adt, D, (int)(rows_per_sample * samples), D, K, last ? VT_ACT_NONE : VT_ACT_GELU_TANH,
+                         ad.wp[i]);
     if (last && pos) {   // + position embedding, broadcast over samples: one group per sample
       p.M = (int)rows_per_sample; p.groups = samples; p.a_gs = rows_per_sample * ld; p.c_gs = rows_per_sample * D;
       p.residual = pos; p.ldr = D; p.r_gs = 0;
+      CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt adaptor"));
+    } else {
+      CK(rgemm(c, p, "rdt adaptor"));      // few rows (the state adaptor inside the denoise loop): the packed-weight small-M tile
     }
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt adaptor"));
     cur = o; ld = D; K = D;
   }
   return VT_OK;
 }
 
 // TimestepEmbedder (blocks.py:28-66): sinusoid(cos|sin) -> Linear -> SiLU -> Linear ; t_dev[B] or scalar
-int embed(RCtx& c, const float* t_dev, float t_host, const void* w1, const float* b1, const void* w2, const float* b2, size_t out_off) {
+int embed(RCtx& c, const float* t_dev, float t_host, const void* w1, const float* b1, const void* w2, const float* b2, size_t out_off,
+          const void* w1p = nullptr, const void* w2p = nullptr) {
   const vt_rdt_desc& d = c.h->d;
   const int D = d.hidden;
   CK(vt_k_sinusoid(t_dev, t_host, c.ws + c.w.sin, d.adt, c.B, 256, 1, 0, 1, c.s));
-  { VtGemmParams p = lin(c.ws + c.w.sin, d.adt, 256, w1, d.cdt, 256, b1, c.ws + c.w.emb_tmp, d.adt, D, c.B, D, 256, VT_ACT_SILU);
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt embed 1")); }
-  { VtGemmParams p = lin(c.ws + c.w.emb_tmp, d.adt, D, w2, d.cdt, D, b2, c.ws + out_off, d.adt, D, c.B, D, D, VT_ACT_NONE);
-    CK(vt_wrap(vt_gemm_launch(p, c.s), "rdt embed 2")); }
+  { VtGemmParams p = lin(c.ws + c.w.sin, d.adt, 256, w1, d.cdt, 256, b1, c.ws + c.w.emb_tmp, d.adt, D, c.B, D, 256, VT_ACT_SILU, w1p);
+    CK(rgemm(c, p, "rdt embed 1")); }
+  { VtGemmParams p = lin(c.ws + c.w.emb_tmp, d.adt, D, w2, d.cdt, D, b2, c.ws + out_off, d.adt, D, c.B, D, D, VT_ACT_NONE, w2p);
+    CK(rgemm(c, p, "rdt embed 2")); }
   return VT_OK;
 }
 
@@ -386,7 +398,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
   if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
   { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, c.h->ffc1_wp);
     CK(rgemm(c, p, "rdt final fc1")); }
-  { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE);
+  { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE, c.h->ffc2_wp);
     CK(rgemm(c, p, "rdt final fc2")); }
   return VT_OK;
 }
@@ -547,7 +559,7 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
     hipLaunchKernelGGL(build_sa_in_kernel, g1((long)B * Hh * 2 * S), dim3(256), 0, s, (const float*)(c.ws + c.w.noisy), action_mask, (void*)(c.ws + c.w.sa_in), B, Hh, S, bf);
     CK(vt_check_launch());
     CK(run_adaptor(c, h->state, c.ws + c.w.sa_in, Hh, B, c.ws + c.w.sa_tmpA, nullptr, c.ws + c.w.tmpA, c.ws + c.w.tmpB));   // action tokens -> sa_tmpA
-    CK(embed(c, nullptr, timesteps[k], h->t_w1, h->t_b1, h->t_w2, h->t_b2, c.w.t_emb));
+    CK(embed(c, nullptr, timesteps[k], h->t_w1, h->t_b1, h->t_w2, h->t_b2, c.w.t_emb, h->t_w1p, h->t_w2p));
     hipLaunchKernelGGL(assemble_x_kernel, g1((long)B * N * D), dim3(256), 0, s, (float*)(c.ws + c.w.x), (const void*)(c.ws + c.w.t_emb), 1,
                        (const void*)(c.ws + c.w.freq_emb), (const void*)(c.ws + c.w.state_tok), (long)D, (const void*)(c.ws + c.w.sa_tmpA), (long)Hh * D,
                        h->x_pos, B, N, D, bf);
