@@ -53,7 +53,8 @@ int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t st
 /* A/B tuning knobs of the GEMM dispatcher (tools/, tests): knob 1 = ring depth of the weights-in-registers tile (0 default, 4, 8);
  * knob 2 = that tile on (1) / off (0); knob 3 = the small-M tile (csrc/vt_gemm_pws.hip) on / off; knob 4 = its k-split factor (0 = choose);
  * knob 5 = timing-only ablation of the weights-in-registers tile (0 = off; results are garbage otherwise: tools/gemm_bench_pw.py --abl);
- * knob 6 = fixed-maximum softmax of the cached cross-attention on (1) / off (0: always the online form). */
+ * knob 6 = fixed-maximum softmax of the cached cross-attention on (1) / off (0: always the online form);
+ * knob 7 = fused U-Net sampler path (vt_unet_fused_pack) on (1) / off (0: the launch-per-op driver). */
 int vt_tune(int knob, int value);
 
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
@@ -122,6 +123,13 @@ int vt_si_sample(vt_unet_t h, float* x, const float* cond, const float* noise, i
 int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise, int n_steps, float beta_max,
                     int gamma_type, int epsilon_type, int sde_type, int backward, float score_weight, float* traj,
                     int B, int T, void* workspace, vt_stream_t stream);
+/* Fused sampler path (csrc/vt_uconv.hip, vt_unet_fused.hip): in the split-bf16 mode (cdt = VT_F32X3, adt = VT_F32, dims % 64 == 0)
+ * every Conv1d resolves GroupNorm + Mish + FiLM + residual of its input in its own prologue — 30 launches per SDE step instead of 67.
+ * It needs a second copy of the convolution weights as pre-split bf16 hi / lo in MFMA fragment order: vt_unet_fused_bytes = size of
+ * that buffer (0 = configuration not supported), vt_unet_fused_pack fills it on the device and switches vt_si_sample* (and
+ * vt_unet_forward with a scalar time) of the handle to the fused path.  The buffer must outlive the handle. */
+size_t vt_unet_fused_bytes(vt_unet_t h);
+int vt_unet_fused_pack(vt_unet_t h, void* buf, vt_stream_t stream);
 /* In-place per-head RMSNorm over 64-wide head slices (timm Attention q_norm/k_norm, models/rdt/blocks.py:150-156):
  * x[token*tok_stride + head*64 + 0..63], mode as vt_rownorm (1 or 2). */
 int vt_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode,

@@ -100,6 +100,50 @@ def dino_engines(dev):
 DINO_TOL = {"fp32": 2e-4, "bf16": 4e-2, "fp16": 6e-3}      # CLS features are O(1..3) after the final LayerNorm
 
 
+@pytest.mark.parametrize("B,T", [(1, 16), (5, 16), (32, 16), (3, 8), (2, 64)])
+def test_unet_fused_path_matches_launch_per_op(dev, unet_engines, B, T):
+    """The fused driver (csrc/vt_uconv.hip: GroupNorm / Mish / FiLM / residual resolved in the consuming convolution's prologue, 30 launches
+    per step) against the launch-per-op driver (vt_tune knob 7) on the same split-bf16 arithmetic: forward of both nets and the 10-step
+    sampler incl. ragged tiles (B not a multiple of the samples per block) and every tile height (T = 8 .. 64)."""
+    from vlatouch import _lib as L
+    lib = L.lib()
+    eng = unet_engines[("ema", "bf16")]
+    assert eng._fused is not None, "the bf16 (split-bf16) engine must carry the fused weight stream"
+    x, cond = cases.unet_inputs(B, T, seed=5)
+    z = torch.from_numpy(np.random.default_rng(11).standard_normal((10, B, T, 10)).astype(np.float32))
+    res = {}
+    try:
+        for on in (0, 1):
+            lib.vt_tune(7, on)
+            f = eng.forward(x, 0.37, cond)
+            xT, traj = eng.sample(x, cond, z, 10, 0.03, record=True)
+            torch.cuda.synchronize()
+            res[on] = (f.cpu(), xT.cpu(), traj.cpu())
+    finally:
+        lib.vt_tune(7, 1)
+    scale = float(res[0][0].abs().max())
+    assert np.isfinite(scale) and scale > 0.1
+    assert max_err(res[1][0], res[0][0]) < 2e-4 * max(1.0, scale), (max_err(res[1][0], res[0][0]), scale)
+    assert max_err(res[1][2][0], res[0][2][0]) == 0.0
+    assert max_err(res[1][2], res[0][2]) < 2e-4
+    assert max_err(res[1][1], res[0][1]) < 2e-4
+
+
+@pytest.mark.parametrize("B", [5, 32])
+def test_unet_fused_path_is_deterministic(dev, unet_engines, B):
+    """Two runs of the fused sampler on the same inputs are bit-identical, at batch sizes whose launches put two workgroups on a CU.
+    (Regression: with hipcc's packed-fp32 VALU instructions in vt_uconv.hip the operand rows of the last quarter wave differed from run to
+    run under co-residency; that file is built with -packed-fp32-ops, csrc/Makefile.)"""
+    eng = unet_engines[("ema", "bf16")]
+    x, cond = cases.unet_inputs(B, 16, seed=7)
+    z = torch.from_numpy(np.random.default_rng(3).standard_normal((10, B, 16, 10)).astype(np.float32))
+    ref_f = eng.forward(x, 0.61, cond).cpu()
+    ref_x = eng.sample(x, cond, z, 10, 0.03).cpu()
+    for _ in range(4):
+        assert torch.equal(eng.forward(x, 0.61, cond).cpu(), ref_f)
+        assert torch.equal(eng.sample(x, cond, z, 10, 0.03).cpu(), ref_x)
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_dino_cls_golden(dev, dino_engines, prec):
     g = G("g3_dino_cls")

@@ -308,6 +308,8 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
   return vt_check_launch();
 }
 
+void vt_unet_fused_tune(int on);
+
 extern "C" int vt_tune(int knob, int value) {
   VtGemmParams dummy{};
   (void)vt_gemm_pw_eligible(dummy);          // environment defaults are read before the first explicit setting
@@ -315,6 +317,7 @@ extern "C" int vt_tune(int knob, int value) {
   if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
   if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
   if (knob == 6) { vt_attn_kvt_tune(value); return VT_OK; }
+  if (knob == 7) { vt_unet_fused_tune(value); return VT_OK; }
   if (knob == 3 || knob == 4) { vt_gemm_pws_tune(knob, value); return VT_OK; }
   return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
 }

@@ -16,38 +16,20 @@
 //   per up-sample (levels-1):    w_even [C][2*C] (taps k=1,k=3)   w_odd [C][2*C] (taps k=0,k=2)   b
 //   final:  fc_w [C0][k*C0]  fc_b  fgn_g  fgn_b  out_w [input_dim][C0]  out_b
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 #include "vt_common.h"
 #include "vt_kernels.h"
 #include "vt_host.h"
-#include "../../include/vlatouch.h"
+#include "vt_uconv.h"
+#include "vt_unet_int.h"
 
 namespace {
 
 struct View { char* p; long ld; long gs; };   // element strides; p is a byte pointer
 
-struct ResBlk {
-  int cin, cin_pad, cout;
-  const void *c0_w, *c1_w, *res_w;
-  const float *c0_b, *g0, *be0, *c1_b, *g1, *be1, *res_b;
-  long film_off;
-};
-
 }  // namespace
-
-struct vt_unet_s {
-  vt_unet_desc d;
-  int nrb;
-  ResBlk rb[32];
-  const void *step_w1, *step_w2, *film_w;
-  const float *step_b1, *step_b2, *film_b;
-  const void* down_w[8]; const float* down_b[8];
-  const void *up_we[8], *up_wo[8]; const float* up_b[8];
-  const void *fc_w, *out_w; const float *fc_b, *fg, *fbe, *out_b;
-  long F;
-  int cmax;
-};
 
 static int es(int dt) { return dt == VT_BF16 ? 2 : 4; }
 
@@ -352,12 +334,26 @@ int make_ctx(Ctx& c, vt_unet_t h, int B, int T, void* ws, vt_stream_t s) {
 
 }  // namespace
 
-size_t vt_unet_workspace_bytes(vt_unet_t h, int B, int T) { return h ? carve(h, B, T).total : 0; }
+// VLATOUCH_UNET_FUSED=0 / vt_tune(7, 0) keeps the sampler on the launch-per-op driver below (A/B)
+static int g_unet_fused = -1;
+static bool fused_enabled() {
+  if (g_unet_fused < 0) { const char* e = getenv("VLATOUCH_UNET_FUSED"); g_unet_fused = (!e || atoi(e) != 0) ? 1 : 0; }
+  return g_unet_fused != 0;
+}
+void vt_unet_fused_tune(int on) { g_unet_fused = on ? 1 : 0; }
+
+size_t vt_unet_workspace_bytes(vt_unet_t h, int B, int T) {
+  if (!h) return 0;
+  const size_t a = carve(h, B, T).total, b = vt_unet_fused_workspace_bytes(h, B, T, 64);
+  return a > b ? a : b;
+}
 
 int vt_unet_forward(vt_unet_t h, const float* x, const float* t_dev, float t_host, const float* cond, float* out,
                     int B, int T, void* workspace, vt_stream_t stream) {
   Ctx c;
   CK(make_ctx(c, h, B, T, workspace, stream));
+  if (!t_dev && fused_enabled() && vt_unet_fused_ok(h, B, T, 1))
+    return vt_unet_fused_run(h, const_cast<float*>(x), cond, &t_host, nullptr, 1, nullptr, nullptr, out, B, T, workspace, (hipStream_t)stream);
   CK(vt_wrap(film_tables(c, t_dev, t_host, false, cond), "unet film tables"));
   CK(vt_wrap(trunk(c, x, out), "unet trunk"));
   return VT_OK;
@@ -409,6 +405,9 @@ int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise
   if (traj) { if (hipMemcpyAsync(traj, x, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "traj copy"); }
   // delta_t = float(1/diffuse_step); n_steps = int(1/delta_t)  (bridge_model.py:335)
   const float dt = (float)(1.0 / (double)n_steps);
+  const bool fused = fused_enabled() && vt_unet_fused_ok(h, B, T, n_steps);
+  float ts[64];
+  VtSdeCoef coef[64];
   for (int k = 1; k <= n_steps; ++k) {
     float t = (float)((double)k / (double)n_steps);
     t = fminf(fmaxf(t, 0.001f), 1.0f - 0.001f);        // t_min clip (bridge_model.py:347-348)
@@ -422,12 +421,18 @@ int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise
     const float noise_scale = dt * sqrtf(2.0f * eps_n);
     // 'vs': b = v - gamma_dot*gamma * (s*gamma_inv) * eps (:369);  'bs': b = b_net output (:306) -> no correction term
     const float gdg = sde_type == 0 ? gder * gam : 0.0f;
+    if (fused) {
+      ts[k - 1] = tn;
+      coef[k - 1] = VtSdeCoef{dt, ginv, gdg, eps_t, noise_scale, beta_max, score_weight * eps_n, backward ? 1 : 0};
+      continue;
+    }
     CK(vt_wrap(film_tables(c, nullptr, tn, k > 1, cond), "si film tables"));
     CK(vt_wrap(trunk(c, x, vs), "si trunk"));
     CK(vt_k_sde_update(x, vs, vs + n, noise ? noise + (long)(k - 1) * n : nullptr, n, dt, ginv, gdg, eps_t, noise_scale, beta_max, score_weight * eps_n,
                        backward ? 1 : 0, s));
     if (traj) { if (hipMemcpyAsync(traj + (long)k * n, x, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "traj copy"); }
   }
+  if (fused) return vt_unet_fused_run(h, x, cond, ts, coef, n_steps, noise, traj, nullptr, B, T, workspace, s);
   return VT_OK;
 }
 

@@ -160,6 +160,12 @@ class UNetEngine:
         assert n == len(W), (n, len(W))
         self._h = C.c_void_p()
         L.check(lib.vt_unet_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_unet_create")
+        # fused sampler path (split-bf16 mode): pre-split hi / lo weights in MFMA fragment order, packed once on the device
+        self._fused = None
+        nb = lib.vt_unet_fused_bytes(self._h)
+        if nb:
+            self._fused = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            L.check(lib.vt_unet_fused_pack(self._h, L.ptr(self._fused), L.stream_ptr(self.device)), "vt_unet_fused_pack")
         self._ws = _Workspace(self.device)
 
     def __del__(self):
