@@ -37,6 +37,7 @@ struct UConvParams {
   int N, cs, S, nsamp, mtiles, ntiles, nw;
   int lds_rstage, lds_stats, lds_par, lds_hi, lds_lo, pitch;    // byte offsets into dynamic LDS; pitch = bytes per operand row
   float eps;
+  long long* tbuf;                 // optional phase time stamps (tools/uconv_phases.py): 8 x s_memrealtime per block, null in the product
 };
 
 struct UFinalParams {              // final_conv.0's GroupNorm+Mish, final_conv.1 (1x1, C -> dim) of both nets and the Euler-Maruyama update
@@ -48,6 +49,8 @@ struct UFinalParams {              // final_conv.0's GroupNorm+Mish, final_conv.
 };
 
 int vt_uconv_launch(const UConvParams& p, int J, size_t lds_bytes, hipStream_t s);
+// phase time stamps of the following launches: buf[launch][2048 blocks][8] (null = off)
+extern "C" int vt_uconv_set_timing(long long* buf, int max_launches);
 int vt_ufinal_launch(const UFinalParams& p, hipStream_t s);
 // fp32 tap-major weights [nets][N][ntaps*cinp] -> the fragment-ordered hi / lo stream described above
 int vt_uconv_pack(const float* Wm, uint16_t* out, int nets, int N, int ntaps, int cinp, int nc32, long out_gs, hipStream_t s);

@@ -11,6 +11,7 @@
 // The 1x1 residual convolution of a res-block rides along with conv0 as extra n-tiles over the same resolved input (own weight stream, own slabs).
 // One block = 16*J output rows (whole samples) x 64 output channels x one slice of `cs` input channels x all taps.
 // Blocks that share a weight slice are placed on one XCD (blockIdx % 8) so the slice leaves HBM / Infinity Cache once.
+#include <type_traits>
 #include "vt_common.h"
 #include "vt_uconv.h"
 
@@ -21,6 +22,21 @@ constexpr int WD = 8;   // weight k-steps in flight per wave (8 x 2 KiB)
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4_t ldv(const float* p) { return *reinterpret_cast<const float4_t*>(p); }
 __device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// sum over each aligned group of `n` lanes (n = 1, 2, 4 ... 64, wave-uniform), result in every lane: DPP inside a row of 16 (no LDS
+// crossbar round trips), two ds_bpermute steps across rows
+__device__ __forceinline__ float seg_sum(float v, int n) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  if (n >= 2) v += dpp(v, std::integral_constant<int, 0xB1>{});    // quad_perm [1,0,3,2]
+  if (n >= 4) v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
+  if (n >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
+  if (n >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+  if (n >= 32) v += __shfl_xor(v, 16, 64);
+  if (n >= 64) v += __shfl_xor(v, 32, 64);
+  return v;
+}
 
 template <int J>
 __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
@@ -41,6 +57,8 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   const bool is_res = nta >= p.ntiles;                // the 1x1 residual convolution: its own n-tiles over the same resolved input
   const int nt = is_res ? nta - p.ntiles : nta;
 
+  long long* tb = (p.tbuf && blockIdx.x < 2048 && tid == 0) ? p.tbuf + (long)blockIdx.x * 8 : nullptr;
+  if (tb) tb[0] = wall_clock64();
   const int cs = p.cs, kcs = cs >> 5;
   const int ntt = is_res ? 1 : p.ntaps;
   const int nsteps = kcs * ntt;
@@ -58,6 +76,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   const USrc S = c_abs >= p.c_split ? p.src[1] : p.src[0];     // by value: fields live in SGPRs instead of kernarg loads inside the loops
   const int c0 = c_abs >= p.c_split ? c_abs - p.c_split : c_abs;
   const int Tin = p.Tin, c4n = cs >> 2;
+  const int c4sh = __builtin_ctz(c4n), tsh = __builtin_ctz(Tin);          // both powers of two (driver: cs = 32 << i, T a power of two)
   const int rows_in = p.nsamp * Tin;
   const int total4 = rows_in * c4n;
   const int b0 = mt * p.nsamp;
@@ -86,7 +105,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
       const int i = tid + 256 * k;
       pv[k] = (float4_t){0.f, 0.f, 0.f, 0.f};
       if (i < npar4) {
-        const int row = i / c4n, c4 = i - row * c4n;
+        const int row = i >> c4sh, c4 = i & (c4n - 1);
         if (row == 0) pv[k] = ldv(gam + c4 * 4);
         else if (row == 1) pv[k] = ldv(bet + c4 * 4);
         else {
@@ -97,6 +116,18 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
       }
     }
   }
+  // identity residual (a plain tensor): at most 4 elements per thread, loaded now, parked in LDS after the gather
+  float4_t rv[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    rv[k] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    const int e = tid + 256 * k;
+    if (S.res_mode == 1 && e < total4) {
+      const int r = e >> c4sh, c4 = e & (c4n - 1);
+      const int samp = r >> tsh, t = r & (Tin - 1);
+      if (b0 + samp < p.B) rv[k] = ldv(rp + ((long)(b0 + samp) * Tin + t) * S.res_ld + c0 + c4 * 4);
+    }
+  }
   // Every value is a sum over the producer's slabs: a latency chain unless the loads of a thread are issued together.  16 loads per
   // round: 4 elements x 4 slabs when a thread owns several elements, 1 element x 16 slabs otherwise; addresses clamped and results
   // zeroed by select so that no load sits behind a branch.  Slabs are added in index order after the bias.
@@ -104,8 +135,8 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     const float4_t z4 = {0.f, 0.f, 0.f, 0.f};
     // element e of the slice -> offset of its 4 channels in the source (0 when the row lies beyond the batch), channel of the bias
     auto locate = [&](int e, bool& ok, int& c) -> long {
-      const int r = e / c4n, c4 = e - r * c4n;
-      const int samp = r / Tin, t = r - samp * Tin;
+      const int r = e >> c4sh, c4 = e & (c4n - 1);
+      const int samp = r >> tsh, t = r & (Tin - 1);
       ok = e < total4 && b0 + samp < p.B;
       c = ok ? c0 + c4 * 4 : c0;
       return ok ? ((long)(b0 + samp) * Tin + t) * gld + c : 0L;
@@ -156,8 +187,8 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   };
   if (S.nslabs == 0 && ((S.ld & 3) || S.cvalid < S.C)) {        // the sampler state itself: [B][T][10] rows, channels >= cvalid are zero
     for (int e = tid; e < total4; e += 256) {
-      const int r = e / c4n, c4 = e - r * c4n;
-      const int samp = r / Tin, t = r - samp * Tin;
+      const int r = e >> c4sh, c4 = e & (c4n - 1);
+      const int samp = r >> tsh, t = r & (Tin - 1);
       const int b = b0 + samp, c = c0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (b < p.B) {
@@ -170,13 +201,17 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   } else {
     gather(sp, S.ld, S.nslabs ? S.nslabs : 1, S.slab, S.nslabs ? sbias : nullptr, reinterpret_cast<float4_t*>(stage));
   }
-  if (S.res_mode == 1) gather(rp, S.res_ld, 1, 0, nullptr, reinterpret_cast<float4_t*>(rstage));
-  else if (S.res_mode == 2) gather(rp, S.res_ld, S.res_nslabs, S.res_slab, rbias, reinterpret_cast<float4_t*>(rstage));
+  if (S.res_mode == 1) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (tid + 256 * k < total4) reinterpret_cast<float4_t*>(rstage)[tid + 256 * k] = rv[k];
+  } else if (S.res_mode == 2) gather(rp, S.res_ld, S.res_nslabs, S.res_slab, rbias, reinterpret_cast<float4_t*>(rstage));
+  if (tb) tb[1] = wall_clock64();      // gathers done (their loads waited for)
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     if (tid + 256 * k < npar4) reinterpret_cast<float4_t*>(smem + p.lds_par)[tid + 256 * k] = pv[k];
   for (int i = tid + 768; i < npar4; i += 256) {          // (not reached with the tile shapes the driver picks: <= 768 parameter float4s)
-    const int row = i / c4n, c4 = i - row * c4n;
+    const int row = i >> c4sh, c4 = i & (c4n - 1);
     float4_t v;
     if (row == 0) v = ldv(S.gamma + (long)net * S.vec_gs + c0 + c4 * 4);
     else if (row == 1) v = ldv(S.beta + (long)net * S.vec_gs + c0 + c4 * 4);
@@ -201,6 +236,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     }
   }
   __syncthreads();
+  if (tb) tb[2] = wall_clock64();
   if (S.cpg > 0) {   // GroupNorm statistics: unit = (sample, group); mean, then centred sum of squares, the unit's values held in registers
     const int cpg4 = S.cpg >> 2, sh = __builtin_ctz(cpg4), gps = cs / S.cpg;
     const int units = p.nsamp * gps;
@@ -225,7 +261,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
         s += (xv[k][0] + xv[k][1]) + (xv[k][2] + xv[k][3]);
       }
       for (int i = li + 8 * tpu; live && i < n4; i += tpu) { const float4_t x = base[(i >> sh) * c4n + (i & (cpg4 - 1))]; s += (x[0] + x[1]) + (x[2] + x[3]); }
-      for (int o = tpu >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+      s = seg_sum(s, tpu);
       const float mean = s * inv_n;
       float q = 0.f;
 #pragma unroll
@@ -239,18 +275,19 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
         const float4_t d = base[(i >> sh) * c4n + (i & (cpg4 - 1))] - mean;
         q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
       }
-      for (int o = tpu >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+      q = seg_sum(q, tpu);
       if (live && li == 0) stats[u] = make_float2(mean, rsqrtf(q * inv_n + p.eps));
     }
     __syncthreads();
   }
+  if (tb) tb[3] = wall_clock64();
   {
     float* mat = (S.mat && nta == 0 && par == 0) ? S.mat + (long)net * S.mat_gs : nullptr;
     const int gps = S.cpg > 0 ? cs / S.cpg : 1;
     const float4_t* par4 = reinterpret_cast<const float4_t*>(smem + p.lds_par);    // gamma | beta | per sample: FiLM scale | FiLM bias
     for (int e = tid; e < total4; e += 256) {
-      const int r = e / c4n, c4 = e - r * c4n;
-      const int samp = r / Tin, t = r - samp * Tin;
+      const int r = e >> c4sh, c4 = e & (c4n - 1);
+      const int samp = r >> tsh, t = r & (Tin - 1);
       const int b = b0 + samp;
       const int c = c0 + c4 * 4;
       float4_t y = reinterpret_cast<const float4_t*>(stage)[e];
@@ -275,6 +312,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   }
   __syncthreads();
 
+  if (tb) tb[4] = wall_clock64();
   // ------------------------------------------------------------------ k-loop (no barrier: LDS is read-only from here on)
   int abase[J];
 #pragma unroll
@@ -323,6 +361,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   for (int d = 0; d < WD; ++d)
     if (s0 + d < nsteps) step(wh[d], wl[d]);
 
+  if (tb) { asm volatile("" : "+v"(acc[0])); tb[5] = wall_clock64(); }
   // ------------------------------------------------------------------ epilogue: lane holds rows m = j*16 + l15, channels n0 + g*4 .. +3
   const int n = nt * 64 + wave * 16 + g * 4;
   float* ob = (is_res ? p.rout + (long)net * p.rout_gs + (long)slice * p.rout_slab : p.out + (long)net * p.out_gs + (long)slice * p.out_slab) + n;
@@ -335,6 +374,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     const long orow = ((long)b * p.Tq + t) * p.omul + par;
     *reinterpret_cast<float4*>(ob + orow * p.ldc) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }
+  if (tb) { tb[6] = wall_clock64(); tb[7] = (long long)((nta << 20) | (slice << 8) | J); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------
@@ -426,14 +466,22 @@ __global__ __launch_bounds__(1024) void ufinal_kernel(const UFinalParams p) {
     }
   }
   __syncthreads();
-  if (live) {   // out[t][d] = sum_c act[t][c] W[d][c] + b[d]: a wave per row, lanes over channels
-    for (int t = w8; t < T; t += 8) {
-      for (int d = 0; d < p.dim; ++d) {
-        float s = 0.f;
-        for (int c = lane; c < C; c += 64) s += act[t * C + c] * wl[d * C + c];
-        s = wave_sum(s);
-        if (lane == 0) outv[net][t * 16 + d] = s + outb[net][d];
+  if (live) {   // out[t][d] = sum_c act[t][c] W[d][c] + b[d]: a wave per row, lanes over channels; the dim partial sums reduce together
+    for (int t = w8; t < T; t += 8) {              // (one butterfly of 6 steps over 16 independent values, not 16 dependent butterflies)
+      float s[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) s[d] = 0.f;
+      for (int c = lane; c < C; c += 64) {
+        const float a = act[t * C + c];
+#pragma unroll
+        for (int d = 0; d < 16; ++d) if (d < p.dim) s[d] += a * wl[d * C + c];
       }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int d = 0; d < 16; ++d) s[d] += __shfl_xor(s[d], o, 64);
+#pragma unroll
+      for (int d = 0; d < 16; ++d) if (lane == d && d < p.dim) outv[net][t * 16 + d] = s[d] + outb[net][d];
     }
   }
   __syncthreads();
@@ -498,7 +546,13 @@ __global__ void usin_kernel(const USinArgs a, int n, float* __restrict__ out, in
 
 }  // namespace
 
-int vt_uconv_launch(const UConvParams& p, int J, size_t lds_bytes, hipStream_t s) {
+static long long* g_tbuf = nullptr;
+static int g_tmax = 0, g_tidx = 0;
+extern "C" int vt_uconv_set_timing(long long* buf, int max_launches) { g_tbuf = buf; g_tmax = max_launches; g_tidx = 0; return VT_OK; }
+
+int vt_uconv_launch(const UConvParams& p_in, int J, size_t lds_bytes, hipStream_t s) {
+  UConvParams p = p_in;
+  p.tbuf = (g_tbuf && g_tidx < g_tmax) ? g_tbuf + (long)(g_tidx++) * 2048 * 8 : nullptr;
   static const bool attr_set = [] {      // tiles may use more than the default 64 KiB of dynamic LDS
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;

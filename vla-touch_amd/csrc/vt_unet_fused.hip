@@ -9,6 +9,7 @@
 //   * final_conv.1 (1x1 to the action dims) of both nets and the Euler-Maruyama update are one small kernel (vt_ufinal).
 // Res-block outputs that a later launch needs as a plain tensor (identity residuals, skip connections) are written by the first consumer.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 #include "vt_common.h"
 #include "vt_kernels.h"
@@ -26,6 +27,9 @@ struct Tile { int J, cs, S, nsamp, mtiles; size_t lds; int l_r, l_st, l_par, l_h
 // wave) costs ~0.1 us — the CU's operand ingest, not the MFMAs; every round of the CONSUMER's prologue gather (16 loads in flight) ~1.5 us, and
 // the number of rounds grows with the slices this launch writes; more than two blocks per CU run in waves.
 bool pick_tile(int B, int Tin, int Tq, int Ntiles, int ntaps, int Ctot, int cmin, int unit, int groups, bool has_res_in, Tile* out) {
+  static const double t_step = [] { const char* e = getenv("VLATOUCH_UC_TSTEP"); return e ? atof(e) : 0.1; }();
+  static const double t_round = [] { const char* e = getenv("VLATOUCH_UC_TROUND"); return e ? atof(e) : 1.5; }();
+  static const double blk_cap = [] { const char* e = getenv("VLATOUCH_UC_BLOCKS"); return e ? atof(e) : 512.0; }();
   double best_cost = 1e30;
   Tile bt;
   bool found = false;
@@ -42,8 +46,8 @@ bool pick_tile(int B, int Tin, int Tq, int Ntiles, int ntaps, int Ctot, int cmin
       const long blocks = (long)groups * mtiles * Ntiles * S;
       const int ne = (rows_in * cs + 1023) / 1024;
       const int rounds = ne > 2 ? ((ne + 3) / 4) * ((S + 3) / 4) : ne * ((S + 15) / 16);
-      double cost = ntaps * (cs / 32) * (J == 4 ? 0.13 : 0.1) + 1.5 * rounds;
-      if (blocks > 512) cost *= (double)blocks / 512.0;
+      double cost = ntaps * (cs / 32) * (J == 4 ? 1.3 : 1.0) * t_step + t_round * rounds;
+      if (blocks > blk_cap) cost *= (double)blocks / blk_cap;
       if (cost < best_cost) {
         best_cost = cost;
         Tile t;
