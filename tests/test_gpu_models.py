@@ -129,6 +129,36 @@ def test_unet_fused_path_matches_launch_per_op(dev, unet_engines, B, T):
     assert max_err(res[1][1], res[0][1]) < 2e-4
 
 
+@pytest.mark.parametrize("dims,k,cond", [((64, 128, 128), 5, 256), ((128, 256), 3, 64), ((64, 64, 128, 256), 5, 128)])
+def test_unet_fused_path_other_architectures(dev, dims, k, cond):
+    """The fused driver on U-Nets other than the controller's (256, 512, 512): narrow levels (one 64-channel n-tile, groups of 8 .. 32
+    channels), two and four levels, kernel size 3, another condition width, against the launch-per-op driver and the oracle."""
+    from oracle import unet1d
+    from vlatouch import _lib as L
+    from vlatouch import synth
+    from vlatouch.engine import UNetEngine
+    lib = L.lib()
+    shapes = synth.si_net_shapes(10, cond, down_dims=dims, k=k)
+    sd = cases.sd_torch(shapes, prefix=f"si-{len(dims)}-{dims[0]}-{k}.")
+    eng = UNetEngine(split_nets(sd), global_cond_dim=cond, down_dims=dims, kernel_size=k, precision="bf16", device=dev)
+    assert eng._fused is not None
+    B, T = 6, 16
+    g = np.random.default_rng(21)
+    x = torch.from_numpy(g.standard_normal((B, T, 10)).astype(np.float32))
+    c = torch.from_numpy(g.standard_normal((B, cond)).astype(np.float32))
+    res = {}
+    try:
+        for on in (0, 1):
+            lib.vt_tune(7, on)
+            res[on] = eng.forward(x, 0.42, c).cpu()
+    finally:
+        lib.vt_tune(7, 1)
+    ref_v = unet1d.unet_forward(sd, "v_net.", x, torch.full((B,), 0.42), c, n_down=len(dims))
+    scale = max(1.0, float(ref_v.abs().max()))
+    assert max_err(res[1], res[0]) < 2e-4 * scale, (max_err(res[1], res[0]), scale)
+    assert max_err(res[1][0], ref_v.numpy()) < 3e-2 * scale
+
+
 @pytest.mark.parametrize("B", [5, 32])
 def test_unet_fused_path_is_deterministic(dev, unet_engines, B):
     """Two runs of the fused sampler on the same inputs are bit-identical, at batch sizes whose launches put two workgroups on a CU.

@@ -65,6 +65,8 @@ def lzf_decompress_py(src: bytes, out_len: int) -> bytes:
         else:
             ln = ctrl >> 5
             ref = op - ((ctrl & 0x1F) << 8) - 1
+            if ip + (2 if ln == 7 else 1) > n:
+                raise ValueError("lzf: truncated back reference")
             if ln == 7:
                 ln += src[ip]; ip += 1
             ref -= src[ip]; ip += 1
@@ -298,7 +300,10 @@ class Dataset:
             if fid == LZF_FILTER:
                 raw = lzf_decompress(raw, nbytes)
             elif fid == GZIP_FILTER:
-                raw = zlib.decompress(raw)
+                d = zlib.decompressobj()
+                raw = d.decompress(raw, nbytes)                # never inflate beyond the chunk the dataset declares
+                if d.unconsumed_tail or not d.eof:
+                    raise ValueError("gzip chunk larger than the dataset's chunk size")
             elif fid == SHUFFLE_FILTER:
                 es = cd[0] if cd else self.dtype.itemsize
                 a = np.frombuffer(raw, dtype=np.uint8)
@@ -360,7 +365,9 @@ class Dataset:
     def __getitem__(self, key):
         if not hasattr(self, "_cache"):
             self._cache = self.read()
-        return self._cache[key] if key is not Ellipsis and key != () else self._cache
+        if key is Ellipsis or (isinstance(key, tuple) and len(key) == 0):
+            return self._cache
+        return self._cache[key]
 
     def __array__(self, dtype=None, copy=None):
         a = self[...]
@@ -518,7 +525,8 @@ def _object_header(msgs: Sequence[bytes]) -> bytes:
 
 
 def _write_dataset(w: _Writer, arr: np.ndarray, compression: Optional[str]) -> int:
-    arr = np.ascontiguousarray(arr)
+    arr = np.asarray(arr)
+    arr = arr if arr.ndim == 0 else np.ascontiguousarray(arr)     # ascontiguousarray would promote a scalar to shape (1,)
     if arr.dtype == np.bool_:
         arr = arr.astype(np.uint8)
     shape = arr.shape

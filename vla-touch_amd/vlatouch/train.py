@@ -514,6 +514,7 @@ class _Optimizer:
         [lr, 1-b1^t, sqrt(1-b2^t), 1-ema_decay_t]) selects the kernels that read the step-dependent scalars from memory (graph replay)."""
         if hyper is None:
             self.step_count += 1
+            self.ema_updates = getattr(self, "ema_updates", 0) + 1
         lib, dev = L.lib(), self.device
         for name, p, g in self._all_params():
             if g is None:
@@ -537,7 +538,7 @@ class _Optimizer:
                                            _sp(dev)), "vt_adamw_ema_multi")
             return
         for name, sh in self.shadow.items():
-            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self._shadow_source(name)), sh.numel(), self._ema_decay(self.step_count), _sp(dev)), "vt_ema_update")
+            L.check(lib.vt_ema_update(L.ptr(sh), L.ptr(self._shadow_source(name)), sh.numel(), self._ema_decay(self.ema_updates), _sp(dev)), "vt_ema_update")
 
     # ---- the whole step as one hipGraph (the eager step is a dependent chain of hundreds to thousands of launches issued from Python)
     def _capture_prep(self, **static: torch.Tensor) -> None:
@@ -557,13 +558,14 @@ class _Optimizer:
 
     def _replay(self, **inputs) -> None:
         if getattr(self, "_graph", None) is None:
-            raise RuntimeError("call capture(...) first")
+            raise RuntimeError("call capture(...) first (a captured step is invalidated when parameters / EMA shadows are reloaded)")
         for k, v in inputs.items():
             v = torch.as_tensor(v)
             # a pinned host tensor stays the caller's: an asynchronous copy would still be reading it when the caller refills it for the
             # next step (replays are enqueued back to back), so that one case is copied synchronously
             self._st[k].copy_(v.reshape(self._st[k].shape), non_blocking=not (v.device.type == "cpu" and v.is_pinned()))
         self.step_count += 1
+        self.ema_updates = getattr(self, "ema_updates", 0) + 1
         # the step scalars travel through a RING of pinned slots, each guarded by the event recorded behind its last H2D copy: with one
         # slot, the copy queued for step n would still be waiting behind step n-1's graph when the host writes step n+1's values
         slot = self.step_count % len(self._hyper_ring)
@@ -571,7 +573,7 @@ class _Optimizer:
         if ev is not None:
             ev.synchronize()
         host = self._hyper_ring[slot]
-        L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.step_count),
+        L.check(L.lib().vt_train_hyper(self.lr, self.betas[0], self.betas[1], self.step_count, self._ema_decay(self.ema_updates),
                                        L.ptr(host)), "vt_train_hyper")
         self._hyper.copy_(host, non_blocking=True)
         ev = torch.cuda.Event()
@@ -599,6 +601,7 @@ class SITrainer(_Optimizer):
         self.mlp = TrainMLP(mlp_sd, self.device) if mlp_sd is not None else None
         self.lr, self.wd, self.betas, self.eps, self.ema_decay = lr, weight_decay, betas, eps, ema_decay
         self.step_count = 0
+        self.ema_updates = 0
         self._m: Dict[str, torch.Tensor] = {}
         self._v: Dict[str, torch.Tensor] = {}
         self.shadow = {f"{n}.{k}": v.clone() for n, u in self.nets.items() for k, v in u.p.items()}     # EMA covers net.parameters()
@@ -689,7 +692,10 @@ class SITrainer(_Optimizer):
             tmp = TrainUNet({k[len(n) + 1:]: v for k, v in ema_sd.items() if k.startswith(n + ".")}, self.device)
             for k, v in tmp.p.items():
                 self.shadow[f"{n}.{k}"] = v
-        self.step_count = int(num_updates)
+        # torch_ema's warm-up counter only: the AdamW step t (bias corrections) stays with the optimizer state, which a checkpoint of the
+        # reference does not carry (fresh moments <-> t restarts at 0, bridge_train.py saves no optimizer.pt)
+        self.ema_updates = int(num_updates)
+        self._graph = None          # a captured step holds the old shadow tensors' addresses: capture again before the next replay
 
     def net_grads(self):
         return OrderedDict((f"{n}.{k}", v) for n, u in self.nets.items() for k, v in u.grads().items())
@@ -739,6 +745,7 @@ class LstmTrainer(_Optimizer):
         self.lr, self.base_lr, self.wd, self.betas, self.eps = lr, lr, weight_decay, betas, eps
         self.p_lstm, self.p_head = lstm_dropout, head_dropout
         self.step_count = 0
+        self.ema_updates = 0
         self._m: Dict[str, torch.Tensor] = {}
         self._v: Dict[str, torch.Tensor] = {}
 
