@@ -89,6 +89,11 @@ def broadcast_controller_weights(ctrl, src: int = 0) -> int:
     # cached position-embedding tables are derived from weights: broadcast them too once they exist
     ts += list(ctrl.image_encoder.engine._pos_cache.values())
     n = broadcast_tensors(ts, src)
+    # derived copies follow the received weights: the fused sampler path's pre-split convolution weights are re-packed locally
+    # (device-side, no extra traffic on the links)
+    net = ctrl.diffusion_model
+    nets = ("v_net", "s_net") if net.sde_type == "vs" else ("b_net", "s_net")
+    net._sampler_engine(nets, torch.device(ctrl.device)).repack()
     for k, v in ctrl.stats.items():
         broadcast_tensors([v], src)
     return n

@@ -165,7 +165,7 @@ class UNetEngine:
         nb = lib.vt_unet_fused_bytes(self._h)
         if nb:
             self._fused = torch.empty(nb, dtype=torch.uint8, device=self.device)
-            L.check(lib.vt_unet_fused_pack(self._h, L.ptr(self._fused), L.stream_ptr(self.device)), "vt_unet_fused_pack")
+            self.repack()
         self._ws = _Workspace(self.device)
 
     def __del__(self):
@@ -177,6 +177,12 @@ class UNetEngine:
 
     def _workspace(self, B: int, T: int) -> torch.Tensor:
         return self._ws.get(L.lib().vt_unet_workspace_bytes(self._h, B, T))
+
+    def repack(self) -> None:
+        """Rebuild the derived weight copy of the fused path from `self._weights` (after they were overwritten in place, e.g. by the
+        one-time broadcast of rank 0's weights, vlatouch/dist.py)."""
+        if self._fused is not None:
+            L.check(L.lib().vt_unet_fused_pack(self._h, L.ptr(self._fused), L.stream_ptr(self.device)), "vt_unet_fused_pack")
 
     def forward(self, x: torch.Tensor, t, cond: torch.Tensor) -> torch.Tensor:
         """x [B,T,dim], t scalar or [B], cond [B,G]  ->  [nets,B,T,dim] fp32."""
