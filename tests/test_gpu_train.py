@@ -138,7 +138,9 @@ def test_trainer_mirror_steps_sync_and_checkpoint_round_trip(tmp_path):
         assert torch.equal(ctrl2.diffusion_model.net.state_dict()[k].cpu(), v.cpu()), k
     for a, b in zip(ctrl.diffusion_model.ema.shadow_params, ctrl2.diffusion_model.ema.shadow_params):
         assert torch.equal(a.cpu(), b.cpu())
-    assert tr2.trainer.step_count == 12
+    # the checkpoint carries torch_ema's num_updates but (like the reference, which saves no optimizer.pt) no AdamW state: the EMA warm-up
+    # counter resumes, the AdamW step t starts again at 0 with its fresh moments
+    assert tr2.trainer.ema_updates == 12 and tr2.trainer.step_count == 0
     l2, _ = tr2.eval_step(batch, t, z)
     assert abs(l2 - l1) < 1e-5 * max(1.0, abs(l1)), (l1, l2)
     out = ctrl2.predict(batch["states"][:, 1], batch["vla_actions"], batch["images_cam1"][:, -1], batch["images_cam2"][:, -1], batch["forces"][:, 1])

@@ -98,7 +98,7 @@ class DiffusionControllerTrainer:
         dm = self.controller.diffusion_model
         dm.net.load_state_dict(self.trainer.net_state_dict())
         ema_sd = self.trainer.ema_state_dict()
-        dm.ema.load_state_dict({"decay": dm.ema.decay, "num_updates": self.trainer.step_count,
+        dm.ema.load_state_dict({"decay": dm.ema.decay, "num_updates": self.trainer.ema_updates,
                                 "shadow_params": [ema_sd[k] for k in dm.net.state_dict().keys()], "collected_params": None})
         self.controller.state_encoder.load_state_dict(self.trainer.mlp.state_dict())
         dm._sampler = None
