@@ -294,7 +294,7 @@ def main():
         # ---- roofline leg: one eager step with HIP events around every launch of the dominant GEMM kernel
         lib = L.lib()
         prof = {}
-        for mode in (2, 3, 4):       # 2 = 256-square GEMM tile, 3 = 160 / 128-column GEMM tiles, 4 = cached cross-attention (one eager step each)
+        for mode in (2, 3, 4, 6):    # 2 = 256-square GEMM tile, 3 = 160 / 128-column GEMM tiles, 4 = cached cross-attention, 6 = fused U-Net convolution (one eager step each)
             lib.vt_prof_enable(mode)
             step()
             stream.synchronize()
@@ -410,6 +410,17 @@ def main():
                 "traffic": (round(pmc["attn_kvt"]["per_launch_bytes"] / 1e9, 4) if "attn_kvt" in pmc else None),
                 "traffic_unit": "GB per launch averaged over image- and language-layer calls (PMC 2*FETCH_SIZE + WRITE_SIZE)",
                 "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3)}
+    r_uc = None
+    if prof.get(6, (0, 0, 0, 0))[3] > 0 and prof[6][0] > 0:
+        ms_, fl_, by_, n_ = prof[6]
+        r_uc = {"kernel": "uconv_kernel (fused conditional 1-D U-Net convolution of the pi_I sampler: GroupNorm + Mish + FiLM + residual of the input resolved in "
+                          "the prologue, split-bf16 MFMA with weights streamed global -> VGPR; a dependent chain of 300 launches per refined batch)",
+                "bound": "mfma", "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2),
+                "algorithmic_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
+                "achieved_GBs": round(by_ / (ms_ * 1e-3) / 1e9, 1), "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3),
+                "note": "latency-bound by construction (M = batch x T_l <= 512 rows per launch): neither roof is near; tools/uconv_phases.py has the "
+                        "in-kernel phase times", "traffic": None}
     if onbox is not None:
         res["onbox_peaks"] = onbox
         for r in (r_pp, r_gl):
@@ -419,9 +430,10 @@ def main():
                 r["frac_of_onbox_gemm_8192"] = round(r["achieved"] / onbox["bf16_gemm_8192_tflops"], 4)
     if r_pp is not None:
         res["roofline"] = r_pp
-        res["roofline_other"] = [r for r in (r_gl, r_at) if r is not None]
+        res["roofline_other"] = [r for r in (r_gl, r_at, r_uc) if r is not None]
     elif r_gl is not None:
         res["roofline"] = r_gl
+        res["roofline_other"] = [r for r in (r_at, r_uc) if r is not None]
 
     # ---- CPU baseline: the oracle (fp32 torch ops on the host cores), rank 0, N=1 only, on a BOUNDED sample:
     #      pi_I leg on CB episodes; RDT leg on ONE episode (the reference's own schedule: K/V re-projected every step).

@@ -1,7 +1,8 @@
 // vt_prof.h — live per-launch timing of the LDS-DMA GEMM kernels (bench.py's roofline leg): while enabled, every launch of
 // the selected kernel class is bracketed by HIP events recorded on its launch stream.
 //   vt_prof_enable(0) off; (1) both classes; (2) only gemm_pp256_kernel (vt_gemm_pp.hip); (3) only gemm_glds_kernel (vt_gemm_fast.hip);
-//   (4) only the cached cross-attention (vt_attn_kvt.hip); (5) only the register-staged gemm_kernel (vt_gemm.hip)
+//   (4) only the cached cross-attention (vt_attn_kvt.hip); (5) only the register-staged gemm_kernel (vt_gemm.hip);
+//   (6) only the fused U-Net convolution (vt_uconv.hip)
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vt_common.h"

@@ -14,6 +14,7 @@
 #include <type_traits>
 #include "vt_common.h"
 #include "vt_uconv.h"
+#include "vt_prof.h"
 
 namespace {
 
@@ -238,19 +239,20 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   __syncthreads();
   if (tb) tb[2] = wall_clock64();
   if (S.cpg > 0) {   // GroupNorm statistics: unit = (sample, group); mean, then centred sum of squares, the unit's values held in registers
-    const int cpg4 = S.cpg >> 2, sh = __builtin_ctz(cpg4), gps = cs / S.cpg;
+    // cpg, cs (hence groups per slice), the threads per unit are powers of two: shifts, no integer division in this phase
+    const int cpg4 = S.cpg >> 2, sh = __builtin_ctz(cpg4), gsh = __builtin_ctz(cs) - __builtin_ctz(S.cpg), gps = 1 << gsh;
     const int units = p.nsamp * gps;
-    int tpu = 64;
-    while (tpu > 1 && tpu * units > 256) tpu >>= 1;
-    const int upp = 256 / tpu;                       // units per pass
+    int tpu = 64, tsh6 = 6;
+    while (tpu > 1 && tpu * units > 256) { tpu >>= 1; --tsh6; }
+    const int upp = 256 >> tsh6;                     // units per pass
     const int n4 = Tin * cpg4;                       // float4s per unit
     const float inv_n = 1.0f / (float)(n4 * 4);
     const int li = tid & (tpu - 1);
     const float4_t* st4 = reinterpret_cast<const float4_t*>(stage);
     for (int u0 = 0; u0 < units; u0 += upp) {
-      const int u = u0 + tid / tpu;
+      const int u = u0 + (tid >> tsh6);
       const bool live = u < units;
-      const int samp = live ? u / gps : 0, gg = live ? u - samp * gps : 0;
+      const int samp = live ? u >> gsh : 0, gg = live ? u & (gps - 1) : 0;
       const float4_t* base = st4 + (samp * Tin) * c4n + gg * cpg4;
       float4_t xv[8];
       float s = 0.f;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   if (tb) tb[3] = wall_clock64();
   {
     float* mat = (S.mat && nta == 0 && par == 0) ? S.mat + (long)net * S.mat_gs : nullptr;
-    const int gps = S.cpg > 0 ? cs / S.cpg : 1;
+    const int gps = S.cpg > 0 ? cs / S.cpg : 1, cpgsh = S.cpg > 0 ? __builtin_ctz(S.cpg) : 0;
     const float4_t* par4 = reinterpret_cast<const float4_t*>(smem + p.lds_par);    // gamma | beta | per sample: FiLM scale | FiLM bias
     for (int e = tid; e < total4; e += 256) {
       const int r = e >> c4sh, c4 = e & (c4n - 1);
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
       float4_t y = reinterpret_cast<const float4_t*>(stage)[e];
       if (b < p.B) {
         if (S.cpg > 0) {
-          const float2 st = stats[samp * gps + (c4 * 4) / S.cpg];
+          const float2 st = stats[samp * gps + ((c4 * 4) >> cpgsh)];
           y = (y - st.x) * st.y * par4[c4] + par4[c4n + c4];
 #pragma unroll
           for (int i = 0; i < 4; ++i) y[i] = act_apply(y[i], VT_ACT_MISH);
@@ -562,6 +564,13 @@ int vt_uconv_launch(const UConvParams& p_in, int J, size_t lds_bytes, hipStream_
   if (!attr_set || lds_bytes > 160 * 1024) return VT_ERR_LAUNCH;
   const int nw8 = (p.nw + 7) / 8 * 8;
   dim3 grid(nw8 * p.mtiles);
+  // vt_prof class 6: MFMA flops actually issued (3 bf16 products per fp32 product) and the bytes a launch must move at least once
+  // (its weights + the slabs it resolves + the slabs it writes)
+  const double rows = (double)p.B * p.Tq * p.npar, K = (double)p.nc32 * 32 * p.ntaps, Cin = (double)p.nc32 * 32;
+  const double flops = 3.0 * 2.0 * rows * p.N * (K + (p.has_res ? Cin : 0.0)) * p.nets;
+  const double bytes = ((double)p.N * (K + (p.has_res ? Cin : 0.0)) * 4.0 + (double)p.B * p.Tin * Cin * 4.0 * (p_in.src[0].nslabs > 0 ? p_in.src[0].nslabs : 1) +
+                        rows * p.N * 4.0 * p.S * (1 + p.has_res)) * p.nets;
+  VtProfScope prof(6, flops, bytes, s);
   if (J == 4) hipLaunchKernelGGL((uconv_kernel<4>), grid, dim3(256), lds_bytes, s, p);
   else if (J == 2) hipLaunchKernelGGL((uconv_kernel<2>), grid, dim3(256), lds_bytes, s, p);
   else if (J == 1) hipLaunchKernelGGL((uconv_kernel<1>), grid, dim3(256), lds_bytes, s, p);
