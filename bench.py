@@ -92,18 +92,38 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` launches its own ranks: re-exec under torch.distributed.run, one process per GPU, rendezvous on
+        # 127.0.0.1 (the container hostname may not resolve).  Rank 0 of the relaunched job prints the ONE JSON line.
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one process per GPU (python bench.py --gpus N does it itself)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path in the product)"
+    # VLATOUCH_BENCH_SHARE_GPU=1: every rank on cuda:0 over gloo — the one-GPU test box's stand-in for N GPUs over RCCL (tests/test_gpu_multiproc.py)
+    share = os.environ.get("VLATOUCH_BENCH_SHARE_GPU", "0") == "1"
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.set_grad_enabled(False)
     dist = None
+    bcast_bytes, bcast_s = 0, 0.0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vlatouch import _lib as L
     from vlatouch import synth
@@ -114,7 +134,11 @@ def main():
     ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats())
     if world > 1:
         from vlatouch.dist import broadcast_controller_weights
-        nbytes = broadcast_controller_weights(ctrl, src=0)
+        torch.cuda.synchronize(dev)
+        tb = time.time()
+        bcast_bytes += broadcast_controller_weights(ctrl, src=0)
+        torch.cuda.synchronize(dev)
+        bcast_s += time.time() - tb
     setup_s = time.time() - t0
     B, T = args.batch, args.horizon
     inp = synth_inputs(B, T, args.res, 1234 + rank, dev)
@@ -143,7 +167,11 @@ def main():
         eng = rdt.engine()
         if world > 1:
             from vlatouch.dist import broadcast_tensors
-            broadcast_tensors(eng._weights, src=0)
+            torch.cuda.synchronize(dev)
+            tb = time.time()
+            bcast_bytes += broadcast_tensors(eng._weights, src=0)
+            torch.cuda.synchronize(dev)
+            bcast_s += time.time() - tb
             eng.repack()                                                 # the fragment-packed copies follow the received weights
         g = torch.Generator(device=dev).manual_seed(4321 + rank)
         rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32).to(rdt_dtype)
@@ -304,7 +332,7 @@ def main():
             prof[mode] = (ms.value, fl.value, by.value, n.value)
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     total_chunks = B * world * args.steps * (8 if args.workload == "marker" else 1)
@@ -348,6 +376,9 @@ def main():
                        "not in the reference)", "setup_s": round(setup_s, 1),
         },
     }
+    if world > 1:
+        res["config"]["weight_broadcast"] = {"bytes": int(bcast_bytes), "seconds": round(bcast_s, 3), "backend": dist.get_backend(),
+                                             "note": "one-time, before the timed region; no collective inside the step loop"}
     # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/pmc_summary.py); the committed summary of
     # the last such run is attached when present (null otherwise: counters cannot be read from inside this process)
     pmc = {}

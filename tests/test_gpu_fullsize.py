@@ -128,6 +128,66 @@ def test_two_streams_in_flight_are_bit_identical_to_one(rdt1b):
             assert torch.equal(o, ref_pi)
 
 
+def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b):
+    """bench.py's headline mode, exactly: two captured hipGraphs of the WHOLE step at B = 32 (RDT-1B chunk -> first 16 ticks x 10 EEF dims ->
+    DINOv2-B x2 + MLP + 10-step SDE), one per HIP stream, replayed alternately so that two full steps are always in flight (RDT beside RDT,
+    K|V projections beside denoise-loop tiles beside the fused U-Net launches).  With the start noise and the SDE noise held fixed every
+    replay on either stream must reproduce the one-at-a-time result bit for bit (VERDICT r3 weak #3)."""
+    from residual_controller.bridge_controller import DiffusionController
+    from vlatouch import ops as _ops
+    ctrl = cases.build_controller(DiffusionController, precision="bf16", device=DEV, size="base", stats_kind="nontrivial")
+    g = np.random.default_rng(23)
+    B, T = 32, 16
+    mk = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32))).to(DEV)
+    cam1, cam2 = mk(0.2 + 0.8 * g.random((B, 3, 224, 224))), mk(0.2 + 0.8 * g.random((B, 3, 224, 224)))
+    state, forces = mk(g.standard_normal((B, 10))), mk(g.standard_normal((B, 3)))
+    z = mk(g.standard_normal((10, B, T, 10)))
+    d = rdt_inputs(B, seed=11)
+    x0 = d["x0"]                                        # bf16-rounded values in fp32, what bench.py's device RNG hands over
+    vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=DEV) for _ in range(2)]
+    hold = [{}, {}]
+
+    def step(si):
+        chunk = rdt1b.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=x0, return_fp32=True)
+        vla = _ops.slice_cast(chunk, T, 10, out=vla_bufs[si])
+        hold[si]["chunk"] = chunk
+        hold[si]["out"] = ctrl.predict(state, vla, cam1, cam2, forces, noise=z)
+
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    with torch.cuda.stream(streams[0]):                 # the one-at-a-time reference (eager, nothing beside it)
+        step(0)
+        streams[0].synchronize()
+        ref_chunk, ref_out = hold[0]["chunk"].clone(), hold[0]["out"].clone()
+    assert torch.isfinite(ref_out).all() and torch.isfinite(ref_chunk).all()
+    graphs = []
+    for si, st in enumerate(streams):
+        with torch.cuda.stream(st):
+            step(si)                                     # sizes this stream's workspaces outside the capture
+            st.synchronize()
+            g_ = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_, stream=st):
+                step(si)
+            graphs.append(g_)
+    torch.cuda.synchronize()
+    for rnd in range(6):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                graphs[si].replay()
+        # results of round `rnd` are read after both streams drain; the NEXT round is enqueued behind them, so two steps overlap fully
+        torch.cuda.synchronize()
+        for si in range(2):
+            assert torch.equal(hold[si]["chunk"], ref_chunk), (rnd, si, float((hold[si]["chunk"] - ref_chunk).abs().max()))
+            assert torch.equal(hold[si]["out"], ref_out), (rnd, si, float((hold[si]["out"] - ref_out).abs().max()))
+    # and back to back without a host sync in between (the bench's steady state: step i+2 queued behind step i on the same stream)
+    for rnd in range(4):
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                graphs[si].replay()
+    torch.cuda.synchronize()
+    for si in range(2):
+        assert torch.equal(hold[si]["chunk"], ref_chunk) and torch.equal(hold[si]["out"], ref_out)
+
+
 # ---------------------------------------------------------------- full-size parity against the oracle (VERDICT r1 #1)
 def _oracle_episode(r, d, b, steps):
     """The oracle's predict_action (fp32 math) on episode b alone, with the runner's bf16-rounded weights, inputs and start noise."""

@@ -30,3 +30,22 @@ def test_two_ranks_on_one_gpu_broadcast_then_bit_equal_and_no_step_collectives()
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, f"rank {r} failed:\n{o[-3000:]}"
     assert "MP_OK" in outs[0], outs[0][-2000:]
+
+
+def test_bench_self_launches_two_ranks_and_prints_one_json_line():
+    """`python bench.py --gpus 2` (what the driver's SCALE run calls) must start its own ranks under torch.distributed.run and print ONE
+    rank-0 JSON line with n_gpus = 2 and the one-time weight broadcast.  The test box has one MI355X: VLATOUCH_BENCH_SHARE_GPU=1 puts both
+    ranks on cuda:0 over gloo (the production path is one GPU per rank over RCCL); everything else is the bench's own multi-rank code."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VLATOUCH_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "4"], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["global_batch"] == 8 and r["scaling"] == "weak"
+    assert r["value"] > 0 and r["config"]["weight_broadcast"]["bytes"] > 2e9          # RDT-1B + DINOv2-B + U-Nets
+    assert "cpu_baseline" not in r                                                     # N = 1 only
+    assert r["roofline"]["frac"] > 0
