@@ -1,0 +1,142 @@
+"""The persistent 256-square GEMM tile with the in-loop, in-register epilogue (csrc/vt_gemm_pt.hip) against (a) a torch fp32 reference and
+(b) gemm_pp256d_kernel on the same launch (`vt_tune(8, 0)`): row-major 16-bit outputs must be BIT-identical (same accumulation order, same
+epilogue arithmetic), the fused K|V projection's Vt half too; its K half sums the 64 squares of a head row in another order (16 per lane, then
+across 4 lanes), so it may differ from the old kernel by one 16-bit rounding step.  Shapes cover: one tile per block (flat epilogue only), many
+tiles per block (slots inside the next tile's first k-tile), odd k-tile counts (buffer parity flips per tile), ragged M (row range check, V-half
+zero fill), N that is not a multiple of the tile (whole waves out of range)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from vlatouch import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def rnd(shape, seed, dev, dtype=torch.float32, scale=1.0):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    return (torch.randn(shape, generator=g, device=dev) * scale).to(dtype)
+
+
+def both(fn):
+    """fn() with the persistent tile on and off."""
+    from vlatouch import _lib as L
+    lib = L.lib()
+    try:
+        L.check(lib.vt_tune(8, 1), "tune")
+        new = fn()
+        torch.cuda.synchronize()
+        L.check(lib.vt_tune(8, 0), "tune")
+        old = fn()
+        torch.cuda.synchronize()
+    finally:
+        lib.vt_tune(8, 1)
+    return new, old
+
+
+def gelu_ref(y, act):
+    from vlatouch import _lib as L
+    if act == L.ACT_GELU_ERF:
+        return torch.nn.functional.gelu(y)
+    if act == L.ACT_GELU_TANH:
+        return torch.nn.functional.gelu(y, approximate="tanh")
+    return y
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,act", [
+    (16384, 2304, 768, "none"),       # DINOv2-B qkv: 576 tiles, 2.25 per block, N = 9 tiles
+    (16500, 3072, 768, "erf"),        # fc1 + GELU, ragged M (116 rows in the last m-tile)
+    (36000, 1152, 1152, "none"),      # SigLIP qkv-like: N = 4.5 tiles (two waves of the last n-tile out of range), nk = 18
+    (35000, 2048, 576, "tanh"),       # nk = 9: the LDS buffer parity flips from tile to tile
+    (2144, 6144, 2048, "none"),       # 216 tiles on 216 blocks: one tile per block, epilogue entirely in the flat tail
+    (70001, 1024, 512, "erf"),        # M % 4 == 1, 4 n-tiles, 4.3 tiles per block
+])
+def test_persistent_tile_row_major_16bit(dev, dtype, M, N, K, act):
+    from vlatouch import ops, _lib as L
+    code = {"none": L.ACT_NONE, "erf": L.ACT_GELU_ERF, "tanh": L.ACT_GELU_TANH}[act]
+    a = rnd((M, K), 1, dev, dtype)
+    w = rnd((N, K), 2, dev, dtype, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    out = torch.full((M + 3, N), 7.0, dtype=dtype, device=dev)          # 3 guard rows: nothing may be written past row M
+
+    def run():
+        out.fill_(7.0)
+        ops.gemm(a, w, bias, act=code, out=out[:M], out_dtype=dtype)
+        return out.clone()
+    new, old = both(run)
+    assert torch.equal(new[M:], torch.full((3, N), 7.0, dtype=dtype, device=dev))
+    assert torch.equal(new, old), float((new.float() - old.float()).abs().max())
+    ref = gelu_ref(a.float() @ w.float().t() + bias, code)
+    err = float((new[:M].float() - ref).abs().max() / ref.abs().max())
+    assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
+    new2, _ = both(run)
+    assert torch.equal(new, new2)                                        # deterministic
+
+
+def _kv_reference(a, w, bias, gain, mode, M, T):
+    """fp32 K|V projection -> ([H, T*64, 64] K after the per-head RMSNorm, [H, T*64, 64] V), rows >= M zero."""
+    from vlatouch import _lib as L
+    N = w.shape[0]
+    D, H = N // 2, N // 128
+    y = a.float() @ w.float().t() + bias
+    k = y[:, :D].reshape(M, H, 64)
+    var = k.pow(2).mean(-1, keepdim=True) if mode == L.NORM_RMS_MEANSQ else k.var(-1, keepdim=True)
+    k = k * torch.rsqrt(var + 1e-6) * gain
+    v = y[:, D:].reshape(M, H, 64)
+    pad = lambda t: torch.cat([t, torch.zeros(T * 64 - M, H, 64, device=t.device)]).permute(1, 0, 2)
+    return pad(k), pad(v)
+
+
+def _untile(kv, T):
+    """tile stream [H, T, 2, 64, 64] -> K [H, T*64, 64], V [H, T*64, 64] (undoing the Vt tiles' MFMA key order)."""
+    H = kv.shape[0]
+    kk = torch.arange(64, device=kv.device)
+    pos = (kk & 32) | (((kk >> 2) & 3) << 3) | (((kk >> 4) & 1) << 2) | (kk & 3)      # vt_kpos
+    k = kv[:, :, 0].reshape(H, T * 64, 64)
+    v = kv[:, :, 1][:, :, :, pos].permute(0, 1, 3, 2).reshape(H, T * 64, 64)            # [h, t, d, kk] -> [h, t, kk, d]
+    return k, v
+
+
+@pytest.mark.parametrize("M,K,mode", [(70001, 512, "meansq"), (13122, 2048, "var"), (139968 // 4, 2048, "meansq"), (4374, 2048, "meansq")])
+def test_persistent_tile_fused_kv_projection(dev, M, K, mode):
+    from vlatouch import ops, _lib as L
+    N, H = 4096, 32
+    T = (M + 63) // 64
+    m = L.NORM_RMS_MEANSQ if mode == "meansq" else L.NORM_RMS_VAR
+    a = rnd((M, K), 1, dev, torch.bfloat16)
+    w = rnd((N, K), 2, dev, torch.bfloat16, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    gain = rnd((64,), 4, dev) * 0.2 + 1.0
+    # the stream the kernel addresses is [H][T] tile pairs back to back: use an exactly sized buffer and a guard behind it
+    flat = torch.empty(H * T * 2 * 4096 + 8192, dtype=torch.bfloat16, device=dev)
+
+    def kv_view():
+        return flat[: H * T * 2 * 4096].view(H, T, 2, 64, 64)
+
+    def run2():
+        flat.fill_(7.0)
+        ops.gemm(a, w, bias, out=kv_view(), out_dtype=torch.bfloat16, headnorm=(gain, N // 2, None, N // 2, 1e-6, m), cmap=(3, T))
+        return flat.clone()
+    new, old = both(run2)
+    assert torch.equal(new[H * T * 2 * 4096:], torch.full((8192,), 7.0, dtype=torch.bfloat16, device=dev))      # nothing past the stream
+    kn, vn = _untile(new[: H * T * 2 * 4096].view(H, T, 2, 64, 64), T)
+    ko, vo = _untile(old[: H * T * 2 * 4096].view(H, T, 2, 64, 64), T)
+    assert torch.equal(vn[:, :M], vo[:, :M])                                             # V half: bit-identical to the old kernel
+    tail = vn[:, M:]
+    assert bool(((tail == 0) | (tail == 7.0)).all())                                     # rows >= M: zero-filled or untouched, never garbage
+    kd = (kn[:, :M].float() - ko[:, :M].float()).abs()
+    assert float(kd.max()) <= 2.0 ** -6 * float(ko[:, :M].float().abs().max())          # K half: at most a rounding step apart
+    assert float((kd > 0).float().mean()) < 0.02
+    assert bool((kn[:, M:] == 7.0).all())                                                # K rows >= M are not written
+    kr, vr = _kv_reference(a, w, bias, gain, m, M, T)
+    assert float((kn[:, :M].float() - kr[:, :M]).abs().max() / kr.abs().max()) < 1e-2
+    assert float((vn[:, :M].float() - vr[:, :M]).abs().max() / vr.abs().max()) < 1e-2
+    again, _ = both(run2)
+    assert torch.equal(new, again)

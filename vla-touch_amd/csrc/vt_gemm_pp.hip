@@ -321,6 +321,7 @@ bool vt_gemm_pp_eligible(const VtGemmParams& p) {
 }
 
 int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s) {
+  if (vt_gemm_pt_eligible(p)) return vt_gemm_pt_launch(p, s);      // persistent tile walk + in-register epilogue folded into the main loop (vt_gemm_pt.hip)
   const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
   const int per_group = tiles_n * tiles_m, total = per_group * p.groups;
   const int gm = g_vt_gm > 0 ? g_vt_gm : 8;

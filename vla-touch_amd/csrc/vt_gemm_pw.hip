@@ -318,6 +318,7 @@ extern "C" int vt_tune(int knob, int value) {
   if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
   if (knob == 6) { vt_attn_kvt_tune(value); return VT_OK; }
   if (knob == 7) { vt_unet_fused_tune(value); return VT_OK; }
+  if (knob == 8) { vt_gemm_pt_tune(value); return VT_OK; }
   if (knob == 3 || knob == 4) { vt_gemm_pws_tune(knob, value); return VT_OK; }
   return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
 }

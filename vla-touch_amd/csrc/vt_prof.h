@@ -43,6 +43,9 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p);
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p);
 bool vt_gemm_pp_eligible(const VtGemmParams& p);          // vt_gemm_pp.hip: 256-square ping-pong tile
 int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s);
+bool vt_gemm_pt_eligible(const VtGemmParams& p);          // vt_gemm_pt.hip: the same tile, persistent, epilogue on registers inside the main loop
+int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s);
+void vt_gemm_pt_tune(int value);                           // 1 = on (default; env VLATOUCH_PT), 0 = off (gemm_pp256d_kernel takes those launches)
 bool vt_gemm_ppk_eligible(const VtGemmParams& p);         // vt_gemm_ppk.hip: 160 x 128 tile, in-block split-K ping-pong, one round
 int vt_gemm_ppk_launch(const VtGemmParams& p, hipStream_t s);
 bool vt_gemm_pw_eligible(const VtGemmParams& p);          // vt_gemm_pw.hip: 160 x 128 tile, fragment-packed weights streamed global -> VGPR
