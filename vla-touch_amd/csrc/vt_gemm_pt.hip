@@ -124,9 +124,10 @@ __device__ __forceinline__ void mma16z(float4_t& acc, const Frag<half_t>& a, con
 // the output tile a block works on, and everything the epilogue of that tile needs (all wave-uniform)
 struct TileId { int m0, n0; };
 
-template <typename T16, int KIND, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, const int tiles_n, const int tiles_m, const int total_tiles, const int GM) {
-  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+// SWAP (KV kind only): this block walks V-half tiles (columns >= N/2) and runs its MFMAs with the operands exchanged.  `tiles_n`, `total_tiles`
+// count the tiles of ONE role (KV: one half of the columns); `nroles` = 2 for the KV kind: blocks with ((blockIdx.x >> 3) & 1) == 1 are the V role.
+template <typename T16, int KIND, int ACT, bool SWAP>
+__device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int nroles) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // group (row half), column quarter
@@ -135,20 +136,22 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
 
   // ---- persistent tile walk: block b = (XCD x = b & 7, slot s = b >> 3) takes entries s, s + S, s + 2S, ... of XCD x's contiguous band of the tile
   //      order (the order itself — super-rows of GM m-tiles, n-major inside — is gemm_pp256d_kernel's), so the S blocks of an XCD work on neighbouring tiles
-  const int G = gridDim.x;
+  const int G = gridDim.x / nroles;                                  // blocks of this role
+  const int bx = nroles == 2 ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;      // this block's index among them (XCD bits kept)
+  const int n_base = SWAP ? (p.N >> 1) : 0;
   const bool banded = (G & 7) == 0;
   const int S = banded ? (G >> 3) : G;
   const int band = banded ? (total_tiles + 7) / 8 : total_tiles;
-  const int band0 = banded ? (int)(blockIdx.x & 7) * band : 0;
+  const int band0 = banded ? (bx & 7) * band : 0;
   const int bandn = min(band, total_tiles - band0);                 // may be <= 0 for the last XCDs of a tiny grid
-  int idx = banded ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  int idx = banded ? (bx >> 3) : bx;
   if (idx >= bandn) return;
   auto decode = [&](int id) __attribute__((always_inline)) -> TileId {
     const int sr = id / (GM * tiles_n);
     const int gmr = min(GM, tiles_m - sr * GM);
     const int r_in = id - sr * GM * tiles_n;
     const int tn = r_in / gmr, tm = sr * GM + (r_in - tn * gmr);
-    return TileId{tm * BM, tn * BN};
+    return TileId{tm * BM, n_base + tn * BN};
   };
 
   // ---- staging context (of the tile whose units are being issued): buffer resources of its A / W row blocks + per-lane offsets.
@@ -208,22 +211,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
   // ---- epilogue state: the tile being finished (`et`), its parameter slot, whether this wave ran it with swapped operands, the row statistics
   TileId et{0, 0};
   int eslot = 0;
-  bool eswap = false;
+  constexpr bool eswap = SWAP, vswap = SWAP;
   float rstd[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)
 #pragma unroll
     for (int j = 0; j < 4; ++j) rstd[h][j] = 0.f;
 
-  // KV kind: is this wave's head in the V half (columns >= N/2)?  Tile-uniform (BN = 256 divides N/2's boundary: N % 512 == 0 is required).
-  auto is_vhalf = [&](const TileId t) __attribute__((always_inline)) { return KIND == KIND_KV && t.n0 + wn * 64 >= (p.N >> 1); };
 
   // ================================================================ epilogue slots (all on registers; see the header)
   // statistics of the wave's rows JB*16 .. JB*16+63 (K half of the KV kind): x = acc + bias kept in place, rstd per row
   auto epi_stats = [&](auto jb_tag, float (&rs)[4]) {
     constexpr int JB = decltype(jb_tag)::value;
     if constexpr (KIND == KIND_KV) {
-      if (eswap) return;
+      if constexpr (eswap) return;
       const unsigned pa = smem_base + PAR_OFF + (eslot * 8 + wave) * PAR_WAVE + (fresh_lane() >> 4) * 16;
       float4_t b4[4];
       b4[0] = lds_ld128<0>(pa); b4[1] = lds_ld128<64>(pa); b4[2] = lds_ld128<128>(pa); b4[3] = lds_ld128<192>(pa);
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
       char* base = reinterpret_cast<char*>(p.C) + ((long)h * p.cmap_T + t0) * 16384;
       const int nrec = tiles_left >= 2 ? 32768 : (tiles_left == 1 ? 16384 : 0);
       const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, nrec, 0x00020000);
-      if (!eswap) {
+      if constexpr (!eswap) {
         // K half: lane = row j*16 + l15, columns i*16 + g*4 + r.  o = x * (rstd * gain)  (x already holds acc + bias)
         const unsigned ha = smem_base + HN_OFF + fg * 16;
         float4_t g4[2];
@@ -383,7 +384,6 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
   const int arow = wm * 128 + l15, brow = wn * 64 + l15;
   int par = 0;                                     // buffer parity of this tile's k-tile 0 (flips per tile when nk is odd)
   int tseq = 0;
-  bool vswap = is_vhalf(cur);
   TileId nxt = cur;
 
   // one k-tile.  MODE selects the wait counts, which epilogue slots run and (SWITCH) where the staging context moves to the next tile.
@@ -421,10 +421,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
     // 16 MFMAs of one quadrant; FIRST: the ks = 0 MFMAs start from a zero C (the quadrant's previous contents were stored by its slot)
 #define VT_PT_MMA(AF, BF, ah, bh)                                                                                          \
     __builtin_amdgcn_s_setprio(1);                                                                                         \
-    static_for<0, 16>([&](auto n_) __attribute__((always_inline)) {                                                                                       \
+    static_for<0, 16>([&](auto n_) __attribute__((always_inline)) {                                                        \
       constexpr int n = decltype(n_)::value, ks = n >> 3, i = (n >> 2) & 1, j = n & 3;                                      \
       float4_t& c_ = acc[(bh) * 2 + i][(ah) * 4 + j];                                                                       \
-      if (!vswap) {                                                                                                        \
+      if constexpr (!SWAP) {                                                                                               \
         if constexpr (MODE == MODE_FIRST && ks == 0) mma16z(c_, BF[i][ks], AF[j][ks]); else mma16(c_, BF[i][ks], AF[j][ks]); \
       } else {                                                                                                             \
         if constexpr (MODE == MODE_FIRST && ks == 0) mma16z(c_, AF[j][ks], BF[i][ks]); else mma16(c_, AF[j][ks], BF[i][ks]); \
@@ -482,12 +482,11 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
     }
     for (; kt < nk - 2; ++kt) ktile(kt, std::integral_constant<int, MODE_STEADY>{});
     ktile(nk - 2, std::integral_constant<int, MODE_SWITCH>{});
-    et = cur; eslot = tseq & 1; eswap = vswap;       // slots S0 .. S5 finish THIS tile (S2 .. S5 inside the next tile's first k-tile)
+    et = cur; eslot = tseq & 1;                      // slots S0 .. S5 finish THIS tile (S2 .. S5 inside the next tile's first k-tile)
     ktile(nk - 1, std::integral_constant<int, MODE_LAST>{});
     if (!has_next) break;
     cur = nxt; idx = nidx; ++tseq;
     par ^= (nk & 1);
-    vswap = is_vhalf(cur);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();       // pay back the stagger
   // the last tile's remaining slots, back to back; then drain the (never consumed) trailing units before the wave ends
@@ -496,6 +495,20 @@ __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, c
   slot_run(std::integral_constant<int, 4>{});
   slot_run(std::integral_constant<int, 5>{});
   wait_vm<0>();
+}
+
+// KV kind: the K-half and the V-half tiles are walked by DIFFERENT blocks (roles alternate in groups of 8 blocks = one block per XCD), because the
+// V half runs its MFMAs with exchanged operands and that choice has to be compile time for the register allocator: the same 16 (of 32) blocks of an
+// XCD walk the same band of m-tiles in both roles, so the A panel they stream is shared in that XCD's L2.
+template <typename T16, int KIND, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, const int tiles_n, const int tiles_m, const int total_tiles, const int GM) {
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
+  if constexpr (KIND == KIND_KV) {
+    if ((blockIdx.x >> 3) & 1) pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2);
+    else pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2);
+  } else {
+    pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1);
+  }
 }
 
 int g_pt_on = -1;
@@ -526,11 +539,19 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return VT_ERR_LAUNCH;
     g_pt_cus = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256;
   }
-  const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+  const bool kv = p.cmap == 3;
+  const int tiles_n = ((kv ? p.N / 2 : p.N) + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;     // KV: tiles of ONE half (role)
   const int total = tiles_n * tiles_m;
   const int gm = g_vt_gm > 0 ? g_vt_gm : 8;
-  int grid = total < g_pt_cus ? total : g_pt_cus;
-  if (grid >= 8) grid &= ~7;
+  int grid;
+  if (kv) {                                            // two roles: a multiple of 16 blocks, each role at most `total` blocks
+    grid = 2 * total < g_pt_cus ? 2 * total : g_pt_cus;
+    grid &= ~15;
+    if (grid < 16) return VT_ERR_UNSUPPORTED;
+  } else {
+    grid = total < g_pt_cus ? total : g_pt_cus;
+    if (grid >= 8) grid &= ~7;
+  }
   VtProfScope prof(2, p, s);
 #define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm)
   if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
