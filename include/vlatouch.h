@@ -131,6 +131,10 @@ int vt_si_sample_ex(vt_unet_t h, float* x, const float* cond, const float* noise
  * vt_unet_forward with a scalar time) of the handle to the fused path.  The buffer must outlive the handle. */
 size_t vt_unet_fused_bytes(vt_unet_t h);
 int vt_unet_fused_pack(vt_unet_t h, void* buf, vt_stream_t stream);
+/* 1 when vt_si_sample* / vt_unet_forward of this handle take the fused path at (B, T, n_steps): packed weights present, T halves cleanly down the
+ * levels (T <= 64: 16, 32, 48, 64, 24 ...; 48-tick chunks are what scripts/franka_inference_eef.py refines), every convolution of the plan finds a
+ * tile and the final kernel's LDS fits the CU.  0 = the launch-per-op driver runs (same results).  vt_unet_workspace_bytes covers both. */
+int vt_unet_fused_covers(vt_unet_t h, int B, int T, int n_steps);
 /* In-place per-head RMSNorm over 64-wide head slices (timm Attention q_norm/k_norm, models/rdt/blocks.py:150-156):
  * x[token*tok_stride + head*64 + 0..63], mode as vt_rownorm (1 or 2). */
 int vt_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode,

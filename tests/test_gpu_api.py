@@ -208,6 +208,31 @@ def test_predict_edge_shapes_vs_oracle(controllers, B, T, res, layout):
     assert err(got, ref.numpy()) < TOL["fp32"], err(got, ref.numpy())
 
 
+@pytest.mark.parametrize("B", [1, 6])
+def test_predict_48_tick_chunks_vs_oracle(controllers, B):
+    """The reference's second robot cadence: scripts/franka_inference_eef.py refines 48-tick chunks.  End to end against the oracle in
+    both precisions; in the low-precision mode the sampler's U-Nets run on the FUSED path at T = 48 (levels 48 / 24 / 12 on 48-row blocks)."""
+    from oracle import controller as oc
+    from vlatouch import _lib as L
+    T = 48
+    g = np.random.default_rng(480 + B)
+    state = torch.from_numpy(g.standard_normal((B, 10)).astype(np.float32))
+    forces = torch.from_numpy(g.standard_normal((B, 3)).astype(np.float32))
+    vla = torch.from_numpy(g.uniform(0, 1, (B, T, 10)).astype(np.float32))
+    z = torch.from_numpy(g.standard_normal((10, B, T, 10)).astype(np.float32))
+    cam1 = torch.from_numpy((0.2 + 0.8 * g.random((B, 3, 224, 224))).astype(np.float32))
+    cam2 = torch.from_numpy((0.6 * g.random((B, 3, 224, 224))).astype(np.float32))
+    ref = oc.predict(cases.dino_sd("small"), 6, cases.state_encoder_sd(781), cases.si_net_sd("ema"), cases.stats("nontrivial"),
+                     state, vla, cam1, cam2, forces, z)
+    for prec in ("fp32", "bf16"):
+        ctrl = controllers[prec]
+        got = ctrl.predict(state.cuda(), vla.cuda(), cam1.cuda(), cam2.cuda(), forces.cuda(), noise=z.cuda())
+        assert got.shape == (B, T, 10)
+        assert err(got, ref.numpy()) < TOL[prec], (prec, err(got, ref.numpy()))
+    eng = controllers["bf16"].diffusion_model._sampler[1]                # the U-Net pair engine the predict() above sampled with
+    assert L.lib().vt_unet_fused_covers(eng._h, B, T, 10) == 1
+
+
 def test_predict_rejects_horizons_the_unet_cannot_run(controllers):
     """T must be divisible by 4 (two stride-2 downsamplings, conditional_unet_1D.py): the reference fails inside torch.cat on
     the skip connection; here the driver refuses up front."""

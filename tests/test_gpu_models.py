@@ -100,7 +100,7 @@ def dino_engines(dev):
 DINO_TOL = {"fp32": 2e-4, "bf16": 4e-2, "fp16": 6e-3}      # CLS features are O(1..3) after the final LayerNorm
 
 
-@pytest.mark.parametrize("B,T", [(1, 16), (5, 16), (32, 16), (3, 8), (2, 64)])
+@pytest.mark.parametrize("B,T", [(1, 16), (5, 16), (32, 16), (3, 8), (2, 64), (1, 48), (7, 48), (32, 48), (5, 24), (9, 12)])
 def test_unet_fused_path_matches_launch_per_op(dev, unet_engines, B, T):
     """The fused driver (csrc/vt_uconv.hip: GroupNorm / Mish / FiLM / residual resolved in the consuming convolution's prologue, 30 launches
     per step) against the launch-per-op driver (vt_tune knob 7) on the same split-bf16 arithmetic: forward of both nets and the 10-step
@@ -109,6 +109,8 @@ def test_unet_fused_path_matches_launch_per_op(dev, unet_engines, B, T):
     lib = L.lib()
     eng = unet_engines[("ema", "bf16")]
     assert eng._fused is not None, "the bf16 (split-bf16) engine must carry the fused weight stream"
+    # T = 48 / 24 / 12: the 48-tick chunks of scripts/franka_inference_eef.py (levels 48 / 24 / 12 on 48-row blocks) stay on the fused path
+    assert lib.vt_unet_fused_covers(eng._h, B, T, 10) == 1 and lib.vt_unet_fused_covers(eng._h, B, T, 1) == 1
     x, cond = cases.unet_inputs(B, T, seed=5)
     z = torch.from_numpy(np.random.default_rng(11).standard_normal((10, B, T, 10)).astype(np.float32))
     res = {}
@@ -157,6 +159,37 @@ def test_unet_fused_path_other_architectures(dev, dims, k, cond):
     scale = max(1.0, float(ref_v.abs().max()))
     assert max_err(res[1], res[0]) < 2e-4 * scale, (max_err(res[1], res[0]), scale)
     assert max_err(res[1][0], ref_v.numpy()) < 3e-2 * scale
+
+
+@pytest.mark.parametrize("dims,B,T,covered", [((512, 512), 3, 32, False), ((512, 512), 3, 16, True), ((64, 64, 64, 64), 64, 8, True)])
+def test_unet_fused_plan_is_checked_per_shape(dev, dims, B, T, covered):
+    """Shapes the fused plan cannot (or could not) run: dims[0] = 512 at T = 32 needs 172 KB of LDS in the final kernel -> the handle
+    must fall back to the launch-per-op driver instead of failing; (64, 64, 64, 64) at T = 8, B = 64 used to pick a tile with 512 GroupNorm
+    statistics units for a 256-entry LDS region (silently wrong) -> the tile choice is bounded now.  Either way the result equals the
+    launch-per-op driver's."""
+    from vlatouch import _lib as L
+    from vlatouch import synth
+    from vlatouch.engine import UNetEngine
+    lib = L.lib()
+    cond = 128
+    shapes = synth.si_net_shapes(10, cond, down_dims=dims, k=5)
+    sd = cases.sd_torch(shapes, prefix=f"si-plan-{len(dims)}-{dims[0]}.")
+    eng = UNetEngine(split_nets(sd), global_cond_dim=cond, down_dims=dims, kernel_size=5, precision="bf16", device=dev)
+    assert eng._fused is not None
+    assert lib.vt_unet_fused_covers(eng._h, B, T, 1) == (1 if covered else 0)
+    g = np.random.default_rng(31)
+    x = torch.from_numpy(g.standard_normal((B, T, 10)).astype(np.float32))
+    c = torch.from_numpy(g.standard_normal((B, cond)).astype(np.float32))
+    res = {}
+    try:
+        for on in (0, 1):
+            lib.vt_tune(7, on)
+            res[on] = eng.forward(x, 0.42, c).cpu()
+    finally:
+        lib.vt_tune(7, 1)
+    scale = max(1.0, float(res[0].abs().max()))
+    assert np.isfinite(scale)
+    assert max_err(res[1], res[0]) < 2e-4 * scale, (max_err(res[1], res[0]), scale)
 
 
 @pytest.mark.parametrize("B", [5, 32])

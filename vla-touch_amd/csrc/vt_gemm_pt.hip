@@ -211,7 +211,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   // ---- epilogue state: the tile being finished (`et`), its parameter slot, whether this wave ran it with swapped operands, the row statistics
   TileId et{0, 0};
   int eslot = 0;
-  constexpr bool eswap = SWAP, vswap = SWAP;
+  constexpr bool eswap = SWAP;
   float rstd[2][4];
 #pragma unroll
   for (int h = 0; h < 2; ++h)

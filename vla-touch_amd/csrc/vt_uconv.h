@@ -52,6 +52,7 @@ int vt_uconv_launch(const UConvParams& p, int J, size_t lds_bytes, hipStream_t s
 // phase time stamps of the following launches: buf[launch][2048 blocks][8] (null = off)
 extern "C" int vt_uconv_set_timing(long long* buf, int max_launches);
 int vt_ufinal_launch(const UFinalParams& p, hipStream_t s);
+size_t vt_ufinal_lds_bytes(int T, int dim, int C);
 // fp32 tap-major weights [nets][N][ntaps*cinp] -> the fragment-ordered hi / lo stream described above
 int vt_uconv_pack(const float* Wm, uint16_t* out, int nets, int N, int ntaps, int cinp, int nc32, long out_gs, hipStream_t s);
 // sinusoidal embedding of n_steps scalar times [n][dsed] (conditional_unet_1D.py:12-19)

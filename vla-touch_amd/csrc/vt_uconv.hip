@@ -77,7 +77,10 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   const USrc S = c_abs >= p.c_split ? p.src[1] : p.src[0];     // by value: fields live in SGPRs instead of kernarg loads inside the loops
   const int c0 = c_abs >= p.c_split ? c_abs - p.c_split : c_abs;
   const int Tin = p.Tin, c4n = cs >> 2;
-  const int c4sh = __builtin_ctz(c4n), tsh = __builtin_ctz(Tin);          // both powers of two (driver: cs = 32 << i, T a power of two)
+  const int c4sh = __builtin_ctz(c4n);                                    // cs = 32 << i
+  // row -> (sample, tick) for ANY Tin <= 64 (48-tick chunks: Tin = 48 / 24 / 12): r / Tin as a multiply-shift, exact for r < 128 rows per block
+  // (magic = ceil(2^16 / Tin): the error term r * (magic * Tin - 2^16) / (Tin * 2^16) < 128 / 2^16 < 1 / Tin)
+  const int tmagic = (65536 + Tin - 1) / Tin;
   const int rows_in = p.nsamp * Tin;
   const int total4 = rows_in * c4n;
   const int b0 = mt * p.nsamp;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     const int e = tid + 256 * k;
     if (S.res_mode == 1 && e < total4) {
       const int r = e >> c4sh, c4 = e & (c4n - 1);
-      const int samp = r >> tsh, t = r & (Tin - 1);
+      const int samp = (r * tmagic) >> 16, t = r - samp * Tin;
       if (b0 + samp < p.B) rv[k] = ldv(rp + ((long)(b0 + samp) * Tin + t) * S.res_ld + c0 + c4 * 4);
     }
   }
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     // element e of the slice -> offset of its 4 channels in the source (0 when the row lies beyond the batch), channel of the bias
     auto locate = [&](int e, bool& ok, int& c) -> long {
       const int r = e >> c4sh, c4 = e & (c4n - 1);
-      const int samp = r >> tsh, t = r & (Tin - 1);
+      const int samp = (r * tmagic) >> 16, t = r - samp * Tin;
       ok = e < total4 && b0 + samp < p.B;
       c = ok ? c0 + c4 * 4 : c0;
       return ok ? ((long)(b0 + samp) * Tin + t) * gld + c : 0L;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
   if (S.nslabs == 0 && ((S.ld & 3) || S.cvalid < S.C)) {        // the sampler state itself: [B][T][10] rows, channels >= cvalid are zero
     for (int e = tid; e < total4; e += 256) {
       const int r = e >> c4sh, c4 = e & (c4n - 1);
-      const int samp = r >> tsh, t = r & (Tin - 1);
+      const int samp = (r * tmagic) >> 16, t = r - samp * Tin;
       const int b = b0 + samp, c = c0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (b < p.B) {
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     const float4_t* par4 = reinterpret_cast<const float4_t*>(smem + p.lds_par);    // gamma | beta | per sample: FiLM scale | FiLM bias
     for (int e = tid; e < total4; e += 256) {
       const int r = e >> c4sh, c4 = e & (c4n - 1);
-      const int samp = r >> tsh, t = r & (Tin - 1);
+      const int samp = (r * tmagic) >> 16, t = r - samp * Tin;
       const int b = b0 + samp;
       const int c = c0 + c4 * 4;
       float4_t y = reinterpret_cast<const float4_t*>(stage)[e];
@@ -557,6 +560,7 @@ int vt_uconv_launch(const UConvParams& p_in, int J, size_t lds_bytes, hipStream_
   p.tbuf = (g_tbuf && g_tidx < g_tmax) ? g_tbuf + (long)(g_tidx++) * 2048 * 8 : nullptr;
   static const bool attr_set = [] {      // tiles may use more than the default 64 KiB of dynamic LDS
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
     ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
     ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&uconv_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess && ok;
     return ok;
@@ -572,14 +576,21 @@ int vt_uconv_launch(const UConvParams& p_in, int J, size_t lds_bytes, hipStream_
                         rows * p.N * 4.0 * p.S * (1 + p.has_res)) * p.nets;
   VtProfScope prof(6, flops, bytes, s);
   if (J == 4) hipLaunchKernelGGL((uconv_kernel<4>), grid, dim3(256), lds_bytes, s, p);
+  else if (J == 3) hipLaunchKernelGGL((uconv_kernel<3>), grid, dim3(256), lds_bytes, s, p);     // 48 rows: chunks whose levels are multiples of 3 ticks (T = 48 / 24 / 12)
   else if (J == 2) hipLaunchKernelGGL((uconv_kernel<2>), grid, dim3(256), lds_bytes, s, p);
   else if (J == 1) hipLaunchKernelGGL((uconv_kernel<1>), grid, dim3(256), lds_bytes, s, p);
   else return VT_ERR_ARG;
   return vt_check_launch();
 }
 
+// dynamic + static LDS of the final kernel (activations and the 1x1 weights of both nets + its small static arrays): must fit the CU's 160 KiB
+size_t vt_ufinal_lds_bytes(int T, int dim, int C) { return (size_t)2 * (T + dim) * C * 4 + 2 * 64 * 8 + 2 * 64 * 16 * 4 + 2 * 16 * 4; }
+
 int vt_ufinal_launch(const UFinalParams& p, hipStream_t s) {
   if (p.T > 64 || p.dim > 16 || p.nets > 2 || (p.C & 3) || p.C / p.cpg > 64) return VT_ERR_UNSUPPORTED;
+  if (vt_ufinal_lds_bytes(p.T, p.dim, p.C) > 160 * 1024) return VT_ERR_UNSUPPORTED;
+  static const bool attr_set = hipFuncSetAttribute(reinterpret_cast<const void*>(&ufinal_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) == hipSuccess;
+  if (!attr_set) return VT_ERR_LAUNCH;
   hipLaunchKernelGGL(ufinal_kernel, dim3(p.B), dim3(1024), (size_t)2 * (p.T + p.dim) * p.C * 4, s, p);
   return vt_check_launch();
 }

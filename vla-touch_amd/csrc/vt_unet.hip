@@ -342,6 +342,10 @@ static bool fused_enabled() {
 }
 void vt_unet_fused_tune(int on) { g_unet_fused = on ? 1 : 0; }
 
+int vt_unet_fused_covers(vt_unet_t h, int B, int T, int n_steps) { return (h && fused_enabled() && vt_unet_fused_ok(h, B, T, n_steps)) ? 1 : 0; }
+
+// the larger of the two drivers' needs; the fused plan is sized whenever the CONFIGURATION supports it, packed or not (a caller may size first and
+// pack afterwards)
 size_t vt_unet_workspace_bytes(vt_unet_t h, int B, int T) {
   if (!h) return 0;
   const size_t a = carve(h, B, T).total, b = vt_unet_fused_workspace_bytes(h, B, T, 64);

@@ -26,23 +26,26 @@ struct Tile { int J, cs, S, nsamp, mtiles; size_t lds; int l_r, l_st, l_par, l_h
 // Tile choice by a small cost model (us per block, measured orders of magnitude): a k-step (32 channels of one tap, 2 KiB of weights per
 // wave) costs ~0.1 us — the CU's operand ingest, not the MFMAs; every round of the CONSUMER's prologue gather (16 loads in flight) ~1.5 us, and
 // the number of rounds grows with the slices this launch writes; more than two blocks per CU run in waves.
-bool pick_tile(int B, int Tin, int Tq, int Ntiles, int ntaps, int Ctot, int cmin, int unit, int groups, bool has_res_in, Tile* out) {
+// cpg_min: the smallest GroupNorm group width among the sources (0 = no GroupNorm): bounds the statistics units of a block.
+bool pick_tile(int B, int Tin, int Tq, int Ntiles, int ntaps, int Ctot, int cmin, int unit, int cpg_min, int groups, bool has_res_in, Tile* out) {
   static const double t_step = [] { const char* e = getenv("VLATOUCH_UC_TSTEP"); return e ? atof(e) : 0.1; }();
   static const double t_round = [] { const char* e = getenv("VLATOUCH_UC_TROUND"); return e ? atof(e) : 1.5; }();
   static const double blk_cap = [] { const char* e = getenv("VLATOUCH_UC_BLOCKS"); return e ? atof(e) : 512.0; }();
   double best_cost = 1e30;
   Tile bt;
   bool found = false;
-  for (int J = 4; J >= 1; J >>= 1) {
+  for (int J = 4; J >= 1; --J) {
+    if (J == 3 && Tq % 3) continue;                                // 48-row blocks only for levels that are multiples of 3 ticks (T = 48 / 24 / 12 ...)
     if ((16 * J) % Tq) continue;
     const int nsamp = 16 * J / Tq;
-    if (J > 1 && nsamp > B && (8 * J) % Tq == 0) continue;        // a smaller tile still holds whole samples: do not pad rows
+    if (J > 1 && !(J & 1) && nsamp > B && (8 * J) % Tq == 0) continue;        // a smaller tile still holds whole samples: do not pad rows
     const int rows_in = nsamp * Tin;
     const int mtiles = (B + nsamp - 1) / nsamp;
     for (int cs = unit; cs <= cmin && cs <= 256 && rows_in * cs <= 4096; cs *= 2) {
       if (cmin % cs || Ctot % cs) break;
       const int S = Ctot / cs;
       if (S > 64) continue;
+      if (cpg_min > 0 && nsamp * (cs / cpg_min) > 256) continue;    // GroupNorm statistics units of a block: the LDS region holds 256
       const long blocks = (long)groups * mtiles * Ntiles * S;
       const int ne = (rows_in * cs + 1023) / 1024;
       const int rounds = ne > 2 ? ((ne + 3) / 4) * ((S + 3) / 4) : ne * ((S + 15) / 16);
@@ -109,7 +112,9 @@ int fconv(Run& R, const FConv& fc, USrc s0, const USrc* s1, int mat_buf, int Tin
   if (s1 && s1->C < cmin) cmin = s1->C;
   const bool has_res_in = s0.res_mode || (s1 && s1->res_mode);
   Tile t;
-  if (!pick_tile(R.B, Tin, Tq, (fc.N / 64) * (1 + fc.has_res), fc.ntaps, Ctot, cmin, unit, d.nets * npar, has_res_in, &t))
+  int cpg_min = s0.cpg;
+  if (s1 && s1->cpg > 0 && (cpg_min == 0 || s1->cpg < cpg_min)) cpg_min = s1->cpg;
+  if (!pick_tile(R.B, Tin, Tq, (fc.N / 64) * (1 + fc.has_res), fc.ntaps, Ctot, cmin, unit, cpg_min, d.nets * npar, has_res_in, &t))
     return vt_fail(VT_ERR_UNSUPPORTED, "fused conv: no tile for T=%d/%d N=%d C=%d", Tin, Tq, fc.N, Ctot);
   const long Mout = (long)R.B * Tq * omul;
   *S_out = t.S;
@@ -304,23 +309,32 @@ bool config_ok(const vt_unet_s* h) {
   return true;
 }
 
-bool shape_ok(const vt_unet_s* h, int B, int T, int n_steps) {
-  if (B < 1 || n_steps < 1 || n_steps > 64 || T < 1 || T > 64 || (T & (T - 1))) return false;
-  if ((T >> (h->d.n_levels - 1)) < 1) return false;
+// Can EVERY launch of the fused plan run for this (B, T)?  T must halve cleanly down the levels (any T <= 64 whose deepest level is >= 1 tick:
+// 16, 32, 48, 64, 24, ...), every convolution must find a tile (dry plan: the same pick_tile calls as the real run, no launches), and the final
+// kernel's LDS (activations + 1x1 weights of both nets) must fit the CU.  A configuration that fails stays on the launch-per-op driver.
+bool shape_ok(const vt_unet_s* h, int B, int T, int n_steps, size_t* ws_bytes) {
+  if (B < 1 || n_steps < 1 || n_steps > 64 || T < 1 || T > 64) return false;
+  const int L = h->d.n_levels;
+  if (T % (1 << (L - 1))) return false;
+  if (vt_ufinal_lds_bytes(T, h->d.input_dim, h->d.dims[0]) > 160 * 1024) return false;
+  Run R;
+  memset(&R, 0, sizeof(R));
+  R.h = h; R.B = B; R.T = T; R.n_steps = n_steps;
+  if (plan(R) != VT_OK) return false;            // (a failing dry plan only leaves its reason in the thread's last-error string)
+  if (ws_bytes) *ws_bytes = R.total;
   return true;
 }
 
 }  // namespace
 
-bool vt_unet_fused_ok(const vt_unet_s* h, int B, int T, int n_steps) { return h && h->fused && shape_ok(h, B, T, n_steps); }
+// `h->fused` (the packed weights exist) is required to RUN the fused path, not to size its workspace: a caller that sizes the workspace before it
+// packs must get the fused plan's size too (vt_unet_workspace_bytes).
+bool vt_unet_fused_ok(const vt_unet_s* h, int B, int T, int n_steps) { return h && h->fused && config_ok(h) && shape_ok(h, B, T, n_steps, nullptr); }
 
 size_t vt_unet_fused_workspace_bytes(const vt_unet_s* h, int B, int T, int n_steps) {
-  if (!vt_unet_fused_ok(h, B, T, n_steps)) return 0;
-  Run R;
-  memset(&R, 0, sizeof(R));
-  R.h = h; R.B = B; R.T = T; R.n_steps = n_steps;
-  if (plan(R)) return 0;
-  return R.total;
+  size_t total = 0;
+  if (!h || !config_ok(h) || !shape_ok(h, B, T, n_steps, &total)) return 0;
+  return total;
 }
 
 int vt_unet_fused_run(const vt_unet_s* h, float* x, const float* cond, const float* ts, const VtSdeCoef* coef, int n_steps, const float* noise,
