@@ -135,6 +135,9 @@ int vt_unet_fused_pack(vt_unet_t h, void* buf, vt_stream_t stream);
  * levels (T <= 64: 16, 32, 48, 64, 24 ...; 48-tick chunks are what scripts/franka_inference_eef.py refines), every convolution of the plan finds a
  * tile and the final kernel's LDS fits the CU.  0 = the launch-per-op driver runs (same results).  vt_unet_workspace_bytes covers both. */
 int vt_unet_fused_covers(vt_unet_t h, int B, int T, int n_steps);
+/* Workspace bytes of the fused plan at (B, T, n_steps); 0 = the plan cannot run this shape or configuration.  Host-only (no launch, independent
+ * of vt_unet_fused_pack): what vt_unet_fused_covers decides on, and part of vt_unet_workspace_bytes. */
+size_t vt_unet_fused_plan_bytes(vt_unet_t h, int B, int T, int n_steps);
 /* In-place per-head RMSNorm over 64-wide head slices (timm Attention q_norm/k_norm, models/rdt/blocks.py:150-156):
  * x[token*tok_stride + head*64 + 0..63], mode as vt_rownorm (1 or 2). */
 int vt_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode,

@@ -216,3 +216,38 @@ def test_rms_mode_is_an_explicit_choice(monkeypatch):
     assert any("timm==1.0.3" in str(x.message) for x in w)
     with pytest.raises(ValueError):
         rr.resolve_rms_mode("l2", {})
+
+
+def test_fused_unet_plan_coverage_is_decided_per_shape_on_the_host():
+    """vt_unet_fused_plan_bytes dry-runs the fused sampler plan (tile choice per convolution, final-kernel LDS budget) without a GPU: the
+    controller's U-Net (256, 512, 512) is covered at the reference's two cadences (16- and 48-tick chunks, bridge_controller.py /
+    scripts/franka_inference_eef.py) and at T = 8 .. 64; shapes the plan cannot run report 0 and stay on the launch-per-op driver."""
+    import ctypes as C
+    from vlatouch import _lib as L
+    lib = L.lib()
+
+    def handle(dims, cdt=2, adt=0):
+        d = L.UnetDesc()
+        d.nets, d.input_dim, d.input_pad, d.cond_dim, d.dsed, d.n_groups, d.ksize, d.n_levels = 2, 10, 32, 256, 256, 8, 5, len(dims)
+        for i, v in enumerate(dims):
+            d.dims[i] = v
+        d.cdt, d.adt = cdt, adt                         # VT_F32X3 weights, VT_F32 activations: the split-bf16 mode the fused path exists for
+        n = lib.vt_unet_num_weights(C.byref(d))
+        fake = (C.c_void_p * n)(*([0x1000] * n))        # never dereferenced: plan sizing is host arithmetic
+        h = C.c_void_p()
+        L.check(lib.vt_unet_create(C.byref(d), fake, n, C.byref(h)), "vt_unet_create")
+        return h
+    h = handle((256, 512, 512))
+    for B in (1, 5, 32):
+        for T in (8, 12, 16, 24, 32, 48, 64):
+            assert lib.vt_unet_fused_plan_bytes(h, B, T, 10) > 0, (B, T)
+        for T in (10, 18, 50, 68):                      # not a multiple of 4, or past 64 ticks
+            assert lib.vt_unet_fused_plan_bytes(h, B, T, 10) == 0, (B, T)
+    assert lib.vt_unet_workspace_bytes(h, 32, 48) >= lib.vt_unet_fused_plan_bytes(h, 32, 48, 64) > 0      # sized before any vt_unet_fused_pack
+    wide = handle((512, 512))
+    assert lib.vt_unet_fused_plan_bytes(wide, 3, 16, 10) > 0
+    assert lib.vt_unet_fused_plan_bytes(wide, 3, 32, 10) == 0       # final kernel: 2 * (32 + 10) * 512 * 4 B = 172 KB of LDS
+    narrow = handle((64, 64, 64, 64))
+    assert lib.vt_unet_fused_plan_bytes(narrow, 64, 8, 10) > 0      # tile choice bounded to 256 GroupNorm units per block
+    fp32 = handle((256, 512, 512), cdt=0)
+    assert lib.vt_unet_fused_plan_bytes(fp32, 4, 16, 10) == 0       # exact-fp32 mode has no fused path

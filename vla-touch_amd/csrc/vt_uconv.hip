@@ -323,7 +323,8 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int m = j * 16 + l15;
-    const int samp = m / p.Tq, t = m - samp * p.Tq;
+    int samp = m / p.Tq, t = m - samp * p.Tq;
+    if (samp >= p.nsamp) { samp = 0; t = 0; }        // padding rows of a block whose 16 J rows are not whole samples (Tq = 12: 2 x 12 of 32): computed, never stored
     abase[j] = (samp * (Tin + 4) + 2 + t * p.stride) * pitch + g * 16;
   }
   float4_t acc[J];
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     const int m = j * 16 + l15;
     const int samp = m / p.Tq, t = m - samp * p.Tq;
     const int b = b0 + samp;
-    if (b >= p.B) continue;
+    if (b >= p.B || samp >= p.nsamp) continue;
     const long orow = ((long)b * p.Tq + t) * p.omul + par;
     *reinterpret_cast<float4*>(ob + orow * p.ldc) = make_float4(acc[j][0], acc[j][1], acc[j][2], acc[j][3]);
   }

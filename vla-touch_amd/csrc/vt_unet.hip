@@ -74,6 +74,7 @@ int vt_unet_create(const vt_unet_desc* desc, const void* const* w, int n, vt_une
   for (int u = 0; u < L - 1; ++u) { h->up_we[u] = w[i++]; h->up_wo[u] = w[i++]; h->up_b[u] = (const float*)w[i++]; }
   h->fc_w = w[i++]; h->fc_b = (const float*)w[i++]; h->fg = (const float*)w[i++]; h->fbe = (const float*)w[i++];
   h->out_w = w[i++]; h->out_b = (const float*)w[i++];
+  vt_unet_fused_init_meta(h);
   *out = h;
   return VT_OK;
 }
@@ -342,6 +343,7 @@ static bool fused_enabled() {
 }
 void vt_unet_fused_tune(int on) { g_unet_fused = on ? 1 : 0; }
 
+size_t vt_unet_fused_plan_bytes(vt_unet_t h, int B, int T, int n_steps) { return h ? vt_unet_fused_workspace_bytes(h, B, T, n_steps) : 0; }
 int vt_unet_fused_covers(vt_unet_t h, int B, int T, int n_steps) { return (h && fused_enabled() && vt_unet_fused_ok(h, B, T, n_steps)) ? 1 : 0; }
 
 // the larger of the two drivers' needs; the fused plan is sized whenever the CONFIGURATION supports it, packed or not (a caller may size first and

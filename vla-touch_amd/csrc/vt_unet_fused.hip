@@ -36,7 +36,7 @@ bool pick_tile(int B, int Tin, int Tq, int Ntiles, int ntaps, int Ctot, int cmin
   bool found = false;
   for (int J = 4; J >= 1; --J) {
     if (J == 3 && Tq % 3) continue;                                // 48-row blocks only for levels that are multiples of 3 ticks (T = 48 / 24 / 12 ...)
-    if ((16 * J) % Tq) continue;
+    if ((16 * J) % Tq && (Tq % 3 || 16 * J < Tq)) continue;        // whole samples per block; levels of 3 x 2^k ticks may pad the block's last rows
     const int nsamp = 16 * J / Tq;
     if (J > 1 && !(J & 1) && nsamp > B && (8 * J) % Tq == 0) continue;        // a smaller tile still holds whole samples: do not pad rows
     const int rows_in = nsamp * Tin;
@@ -382,6 +382,21 @@ static size_t conv_pack_elems(const vt_unet_s* h, int which, int idx) {   // bf1
   conv_pack_dims(h, which, idx, &N, &ntaps, &cinp, &has_res);
   const int nc32 = (cinp + 31) / 32;
   return (size_t)(N / 16) * nc32 * (ntaps * (which == 3 ? 2 : 1) + has_res) * 1024;
+}
+
+// shapes of every fused convolution (N, taps, packed reduction width, residual stream), known from the descriptor alone: set at vt_unet_create so
+// that the plan can be sized (vt_unet_fused_plan_bytes, vt_unet_workspace_bytes) before — or without — vt_unet_fused_pack
+void vt_unet_fused_init_meta(vt_unet_s* h) {
+  if (!h || !config_ok(h)) return;
+  const int L = h->d.n_levels;
+  auto meta = [&](FConv& fc, int which, int idx) {
+    int N, ntaps, cinp, has_res;
+    conv_pack_dims(h, which, idx, &N, &ntaps, &cinp, &has_res);
+    fc.nc32 = (cinp + 31) / 32; fc.ntaps = ntaps; fc.has_res = has_res; fc.N = N;
+  };
+  for (int i = 0; i < h->nrb; ++i) { meta(h->f_c0[i], 0, i); meta(h->f_c1[i], 1, i); }
+  for (int l = 0; l < L - 1; ++l) { meta(h->f_down[l], 2, l); meta(h->f_up[l], 3, l); }
+  meta(h->f_fc, 4, 0);
 }
 
 size_t vt_unet_fused_bytes(vt_unet_t h) {

@@ -35,6 +35,7 @@ void vt_unet_fused_tune(int on);   // vt_tune knob 7
 // fused driver (vt_unet_fused.hip)
 size_t vt_unet_fused_workspace_bytes(const vt_unet_s* h, int B, int T, int n_steps);
 bool vt_unet_fused_ok(const vt_unet_s* h, int B, int T, int n_steps);
+void vt_unet_fused_init_meta(vt_unet_s* h);       // called by vt_unet_create
 // n_steps evaluations of the nets at the scalar times ts[k] on the evolving state x: with `sde` the Euler-Maruyama update of step k is applied
 // by the last kernel (coefficient arrays indexed by k); without, n_steps must be 1 and vs_out receives the raw net outputs
 struct VtSdeCoef { float dt, gi, gdg, eps_t, noise_scale, d, score_eps; int backward; };

@@ -137,6 +137,7 @@ SIGNATURES = {
     "vt_unet_fused_bytes": (_Z, [_P]),
     "vt_unet_fused_pack": (_I, [_P, _P, _P]),
     "vt_unet_fused_covers": (_I, [_P, _I, _I, _I]),
+    "vt_unet_fused_plan_bytes": (_Z, [_P, _I, _I, _I]),
     "vt_unet_forward": (_I, [_P, _P, _P, _F, _P, _P, _I, _I, _P, _P]),
     "vt_si_sample": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _P, _I, _I, _P, _P]),
     "vt_si_sample_ex": (_I, [_P, _P, _P, _P, _I, _F, _I, _I, _I, _I, _F, _P, _I, _I, _P, _P]),
