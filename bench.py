@@ -49,6 +49,9 @@ def parse():
                     help="full: BASELINE configs[3] = one RDT-1B chunk (5-step DPM-Solver++) + DINOv2 x2 + MLP + interpolant sampler per "
                          "refined chunk; pi_refine: the same without the RDT chunk generator; dino_mlp: configs[1]; rdt: configs[2]")
     ap.add_argument("--rdt-steps", type=int, default=5, help="RDT denoising steps (upstream RDT-1B config: 5)")
+    ap.add_argument("--rms-mode", default="meansq", choices=["meansq", "var"],
+                    help="timm RmsNorm arithmetic of RDT: meansq = timm >= 1.0.9; var = timm <= 1.0.8 incl. the timm==1.0.3 upstream RDT-1B pins (what its "
+                         "released checkpoints need): no score bound exists there, so the cached cross-attention runs its ONLINE softmax")
     ap.add_argument("--lang-len", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--streams", type=int, default=0,
@@ -131,7 +134,9 @@ def main():
 
     # ---- frozen weights: rank 0 generates the deterministic synthetic set, the others receive it over RCCL
     t0 = time.time()
-    ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats())
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):       # the mirrored reference classes print while they build ("init SI without model args"): stdout carries ONE JSON line
+        ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats())
     if world > 1:
         from vlatouch.dist import broadcast_controller_weights
         torch.cuda.synchronize(dev)
@@ -157,7 +162,7 @@ def main():
     if args.workload in ("full", "rdt", "robot"):
         from models.rdt_runner import RDTRunner
         rdt_dtype = torch.bfloat16 if args.precision == "bf16" else torch.float32
-        cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": "meansq"}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
+        cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": args.rms_mode}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
                "state_adaptor": "mlp3x_gelu",
                "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": args.rdt_steps, "beta_schedule": "squaredcos_cap_v2",
                                    "prediction_type": "sample", "clip_sample": False}}
@@ -376,6 +381,12 @@ def main():
                        "not in the reference)", "setup_s": round(setup_s, 1),
         },
     }
+    # end-to-end matrix-pipe fraction: SURVEY 8(d)'s algorithmic GFLOP per chunk (2 MAC, cached condition K/V, no recompute credit) x chunks / wall time
+    gf_chunk = {"full": (1030.0 + 168.0 * args.rdt_steps + 57.0) + 99.3, "rdt": 1030.0 + 168.0 * args.rdt_steps + 57.0, "pi_refine": 99.3, "dino_mlp": 92.6}.get(args.workload)
+    if gf_chunk is not None and args.dino == "base" and args.horizon == 16:
+        tf = gf_chunk * total_chunks / elapsed / 1e3
+        res["end_to_end_mfma"] = {"algorithmic_gflop_per_chunk": round(gf_chunk, 1), "achieved_tflops": round(tf, 1), "peak_tflops": PEAK_BF16_TFLOPS * world,
+                                  "frac": round(tf / (PEAK_BF16_TFLOPS * world), 4), "note": "whole step incl. HBM- and launch-bound phases against the dense bf16 MFMA peak"}
     if world > 1:
         res["config"]["weight_broadcast"] = {"bytes": int(bcast_bytes), "seconds": round(bcast_s, 3), "backend": dist.get_backend(),
                                              "note": "one-time, before the timed region; no collective inside the step loop"}
@@ -441,6 +452,13 @@ def main():
                 "traffic": (round(pmc["attn_kvt"]["per_launch_bytes"] / 1e9, 4) if "attn_kvt" in pmc else None),
                 "traffic_unit": "GB per launch averaged over image- and language-layer calls (PMC 2*FETCH_SIZE + WRITE_SIZE)",
                 "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3)}
+        if rdt is not None:      # which softmax ran: the fixed-maximum form needs a load-time score bound per block (mean-square RmsNorm only) <= 40
+            sb = [b for b in rdt.engine().score_bounds]
+            fixed_on = os.environ.get("VLATOUCH_ATTN_FIXEDMAX", "1") != "0"
+            n_fixed = sum(1 for b in sb if 0.0 < b <= 40.0) if fixed_on else 0
+            r_at["softmax"] = "fixed" if n_fixed == len(sb) else ("online" if n_fixed == 0 else f"fixed in {n_fixed} of {len(sb)} blocks")
+            r_at["score_bound_max"] = round(max(sb), 2) if sb else None
+            r_at["rms_mode"] = rdt.rms_mode
     r_uc = None
     if prof.get(6, (0, 0, 0, 0))[3] > 0 and prof[6][0] > 0:
         ms_, fl_, by_, n_ = prof[6]
@@ -448,7 +466,9 @@ def main():
                           "the prologue, split-bf16 MFMA with weights streamed global -> VGPR; a dependent chain of 300 launches per refined batch)",
                 "bound": "mfma", "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "launches_per_step": n_, "avg_launch_us": round(1000 * ms_ / n_, 2),
-                "algorithmic_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
+                "issued_mfma_gflop_per_step": round(fl_ / 1e9, 1), "algorithmic_gflop_per_step": round(fl_ / 3e9, 1),
+                "flop_note": "achieved / frac count the bf16 MFMA flops ISSUED (split-bf16: 3 products per fp32 product); the algorithmic figure is a third",
+                "algorithmic_gbytes_per_step": round(by_ / 1e9, 3),
                 "achieved_GBs": round(by_ / (ms_ * 1e-3) / 1e9, 1), "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3),
                 "note": "latency-bound by construction (M = batch x T_l <= 512 rows per launch): neither roof is near; tools/uconv_phases.py has the "
                         "in-kernel phase times", "traffic": None}

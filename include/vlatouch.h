@@ -52,7 +52,8 @@ int vt_gemm(const void* params, vt_stream_t stream);
 int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t stream);
 /* A/B tuning knobs of the GEMM dispatcher (tools/, tests): knob 1 = ring depth of the weights-in-registers tile (0 default, 4, 8);
  * knob 2 = that tile on (1) / off (0); knob 3 = the small-M tile (csrc/vt_gemm_pws.hip) on / off; knob 4 = its k-split factor (0 = choose);
- * knob 5 = timing-only ablation of the weights-in-registers tile (0 = off; results are garbage otherwise: tools/gemm_bench_pw.py --abl);
+ * knob 5 = timing-only ablation of the weights-in-registers tile (results are garbage: exists only in a build with -DVLATOUCH_BENCH_BUILD,
+ *          tools/gemm_bench_pw.py --abl; the shipped library rejects any value but 0);
  * knob 6 = fixed-maximum softmax of the cached cross-attention on (1) / off (0: always the online form);
  * knob 7 = fused U-Net sampler path (vt_unet_fused_pack) on (1) / off (0: the launch-per-op driver);
  * knob 8 = persistent 256-square GEMM tile with the in-loop epilogue (csrc/vt_gemm_pt.hip) on (1) / off (0: gemm_pp256d_kernel). */

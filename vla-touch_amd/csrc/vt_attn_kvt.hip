@@ -468,7 +468,14 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
 }  // namespace
 
 static int g_vt_attn_fixed = 1;        // VLATOUCH_ATTN_FIXEDMAX / vt_tune(6, .): fixed-maximum softmax where a score bound is known
-void vt_attn_kvt_tune(int value) { g_vt_attn_fixed = value != 0; }
+// the environment default is read ONCE, before the first explicit setting or launch (an explicit vt_tune(6, .) made before the first launch used to be
+// overwritten by the launch's own lazy read of the environment)
+static void attn_env_once() {
+  static const bool init = [] { const char* e = getenv("VLATOUCH_ATTN_FIXEDMAX"); if (e) g_vt_attn_fixed = atoi(e) != 0; return true; }();
+  (void)init;
+}
+void vt_attn_kvt_tune(int value) { attn_env_once(); g_vt_attn_fixed = value != 0; }
+int vt_attn_kvt_fixed_enabled() { attn_env_once(); return g_vt_attn_fixed; }
 
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || (long)p.T * 64 < (long)p.B * p.Nk || p.q_rs % 8) return VT_ERR_ARG;
@@ -484,8 +491,7 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   // VLATOUCH_ATTN_RING: 0 = the 2-stage whole-tile kernel, 4 / 5 = half-tile ring with counted waits (default 5)
   static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
   // fixed-maximum softmax (see attn_kvt_ring_kernel): only with a finite load-time bound small enough that exp(-2B) stays a normal number
-  static const bool init = [] { const char* e = getenv("VLATOUCH_ATTN_FIXEDMAX"); if (e) g_vt_attn_fixed = atoi(e); return true; }();
-  (void)init;
+  attn_env_once();
   const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= 40.f;
 #define VT_KVT_GO(grid) \
   do { if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), 0, s, p); \

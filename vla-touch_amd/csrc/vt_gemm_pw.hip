@@ -271,7 +271,9 @@ __global__ void pack_w32_kernel(const uint16_t* __restrict__ W, const long ldw, 
 
 }  // namespace
 
+#ifdef VLATOUCH_BENCH_BUILD
 static int g_vt_pw_abl = 0;     // vt_tune(5, k): timing-only ablation k of gemm_pw_kernel<bf16, bf16, 4> (0 = off)
+#endif
 static int g_vt_pw_nb = 0;      // ring depth 4 | 8 (VLATOUCH_PW_NB, vt_tune(1, .)); 0 = default
 static int g_vt_pw_on = 1;      // VLATOUCH_PW=0 / vt_tune(2, 0) disables the kernel (A/B against gemm_ppk_kernel / gemm_pp256d_kernel)
 
@@ -294,6 +296,7 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
   const bool c16 = p.c_dtype != VT_F32;
 #define VT_PW_GO(T16, TC) do { if (g_vt_pw_nb == 8) hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 8>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); \
                                else hipLaunchKernelGGL((gemm_pw_kernel<T16, TC, 4>), dim3(total), dim3(256), 0, s, p, tiles_n, per_group, total, gm); } while (0)
+#ifdef VLATOUCH_BENCH_BUILD      // timing-only ablations (garbage results): compiled only into a bench build (make DEFS=-DVLATOUCH_BENCH_BUILD)
   if (g_vt_pw_abl && p.a_dtype == VT_BF16 && c16) {
     const dim3 g(total), b(256);
     if (g_vt_pw_abl == 1) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 1>), g, b, 0, s, p, tiles_n, per_group, total, gm);
@@ -302,6 +305,7 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
     else hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 4>), g, b, 0, s, p, tiles_n, per_group, total, gm);
     return vt_check_launch();
   }
+#endif
   if (p.a_dtype == VT_BF16) { if (c16) VT_PW_GO(bf16_t, bf16_t); else VT_PW_GO(bf16_t, float); }
   else { if (c16) VT_PW_GO(half_t, half_t); else VT_PW_GO(half_t, float); }
 #undef VT_PW_GO
@@ -315,7 +319,11 @@ extern "C" int vt_tune(int knob, int value) {
   (void)vt_gemm_pw_eligible(dummy);          // environment defaults are read before the first explicit setting
   if (knob == 1 && (value == 0 || value == 4 || value == 8)) { g_vt_pw_nb = value; return VT_OK; }
   if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
+#ifdef VLATOUCH_BENCH_BUILD
   if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
+#else
+  if (knob == 5) return value == 0 ? VT_OK : vt_fail(VT_ERR_UNSUPPORTED, "vt_tune(5, .): the timing-only ablations exist only in a bench build (make DEFS=-DVLATOUCH_BENCH_BUILD)");
+#endif
   if (knob == 6) { vt_attn_kvt_tune(value); return VT_OK; }
   if (knob == 7) { vt_unet_fused_tune(value); return VT_OK; }
   if (knob == 8) { vt_gemm_pt_tune(value); return VT_OK; }

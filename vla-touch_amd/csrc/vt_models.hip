@@ -121,9 +121,40 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
     if (cls) CK(vt_k_bcast_row(h->cls_pos0, tok, (long)N * D, Bt, D, s));
   }
   const int M = Bt * N;
+  // The reference consumes only pooler_output = the CLS row of the last layer (visual_encoder.py:88-93): in the LAST block every token still feeds
+  // K and V, but only the CLS row needs a query, the output projection, the MLP and the residual updates (SURVEY 2.1 "last layer prunes to the CLS
+  // query").  VLATOUCH_DINO_CLS_LAST=0 runs the last block on all tokens (A/B; same CLS row up to the summation order of the small-M GEMM tiles).
+  static const bool cls_last_on = [] { const char* e = getenv("VLATOUCH_DINO_CLS_LAST"); return !e || atoi(e) != 0; }();
   for (int l = 0; l < d.layers; ++l) {
     const DinoLayer& L = h->L[l];
+    const bool cls_only = cls_last_on && cls && !d.out_all && l == d.layers - 1;
     CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln1_w, L.ln1_b, M, D, d.eps, VT_NORM_LAYER, s));
+    if (cls_only) {
+      const long tstride = (long)N * D;                 // CLS row of image b = row b * N of the token matrix
+      // K | V of every token (rows Da .. 3 Da of the fused qkv weight) + Q of the CLS rows only
+      { VtGemmParams p = lin(ws + w.xn, d.adt, D, (const char*)L.qkv_w + (size_t)Da * D * es(d.cdt), d.cdt, D, L.qkv_b + Da, ws + w.qkv + (size_t)Da * a, d.adt, 3 * Da,
+                             M, 2 * Da, D, VT_ACT_NONE);
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino kv (last block)")); }
+      { VtGemmParams p = lin(ws + w.xn, d.adt, tstride, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, (long)N * 3 * Da, Bt, Da, D, VT_ACT_NONE);
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino q (CLS rows)")); }
+      { VtAttnParams p;
+        memset(&p, 0, sizeof(p));
+        p.Q = ws + w.qkv; p.K = ws + w.qkv + (size_t)Da * a; p.V = ws + w.qkv + (size_t)2 * Da * a; p.O = ws + w.att;
+        p.q_bs = p.k_bs = p.v_bs = (long)N * 3 * Da; p.q_rs = p.k_rs = p.v_rs = 3 * Da; p.q_hs = p.k_hs = p.v_hs = hd;
+        p.o_bs = Da; p.o_rs = Da;                         // one output row per image, compact [Bt][Da]
+        p.B = Bt; p.H = d.heads; p.Nq = 1; p.Nk = N; p.scale = scale; p.dtype = d.adt; p.hd = hd;
+        CK(vt_wrap(vt_attn_launch(p, s), "dino attention (CLS query)")); }
+      { VtGemmParams p = lin(ws + w.att, d.adt, Da, L.proj_w, d.cdt, Da, L.proj_b, tok, VT_F32, tstride, Bt, D, Da, VT_ACT_NONE);
+        p.colscale = L.ls1; p.residual = tok; p.ldr = tstride;
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino proj (CLS rows)")); }
+      CK(vt_k_rownorm(tok, VT_F32, tstride, ws + w.xn, d.adt, D, L.ln2_w, L.ln2_b, Bt, D, d.eps, VT_NORM_LAYER, s));
+      { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, Dm, Bt, Dm, D, act);
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1 (CLS rows)")); }
+      { VtGemmParams p = lin(ws + w.h1, d.adt, Dm, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tstride, Bt, D, Dm, VT_ACT_NONE);
+        p.colscale = L.ls2; p.residual = tok; p.ldr = tstride;
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2 (CLS rows)")); }
+      continue;
+    }
     { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, 3 * Da, M, 3 * Da, D, VT_ACT_NONE);
       CK(vt_wrap(vt_gemm_launch(p, s), "dino qkv")); }
     { VtAttnParams p;

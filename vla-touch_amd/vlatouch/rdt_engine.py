@@ -97,6 +97,7 @@ class RdtEngine:
                 base = 11 + 21 * i
                 wq, wk = self._weights[base + 12], self._weights[base + 13]
                 bounds[i] = 8.0 * 1.02 * float(wq.abs().max()) * float(wk.abs().max())
+        self.score_bounds = [float(b) for b in bounds]      # 0 = unknown: that block's cross-attention keeps the online softmax
         L.check(L.lib().vt_rdt_set_score_bounds(self._h, bounds, self._depth), "vt_rdt_set_score_bounds")
 
     def repack(self):
