@@ -48,6 +48,8 @@ def case(name, M, N, K, dt, act=L.ACT_NONE, kv=False):
 
 bf, h = torch.bfloat16, torch.float16
 case("rdt cond K|V (B=32 img)", 139968, 4096, 2048, bf, kv=True)
+if "kv" in sys.argv[1:]:
+    sys.exit(0)
 case("rdt img adaptor fc1 gelu", 139968, 2048, 1152, bf, act=L.ACT_GELU_TANH)
 case("dinov2-b qkv", 16384, 2304, 768, h)
 case("dinov2-b fc1 gelu", 16384, 3072, 768, h, act=L.ACT_GELU_ERF)

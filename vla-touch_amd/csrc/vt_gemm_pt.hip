@@ -56,6 +56,14 @@ constexpr int SMEM_BYTES = HN_OFF + 256;
 enum { KIND_KV = 0, KIND_P16 = 1 };
 enum { MODE_STEADY = 0, MODE_FIRST = 1, MODE_SECOND = 2, MODE_SWITCH = 3, MODE_LAST = 4 };
 
+// the epilogue's store; bench builds can turn it into a register sink (VLATOUCH_PT_ABL & 8: what do the stores themselves cost?)
+__device__ __forceinline__ void pt_store(const uint4_t d, const __amdgpu_buffer_rsrc_t rc, const int off, const int abl) {
+#ifdef VLATOUCH_BENCH_BUILD
+  if (abl & 8) { asm volatile("" :: "v"(d), "v"(off)); return; }
+#endif
+  __builtin_amdgcn_raw_buffer_store_b128(d, rc, off, 0, 0);
+}
+
 // compile-time loop: indices are constants by construction (an epilogue slot that the unroller gives up on would index the accumulators
 // dynamically and push all 128 of them to scratch)
 template <int I0, int I1, typename F> __device__ __forceinline__ void static_for(F&& f) {
@@ -89,6 +97,18 @@ template <int OFF> __device__ __forceinline__ float lds_ld32(unsigned addr) {
 __device__ __forceinline__ void lds_wait(float4_t& a, float4_t& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 __device__ __forceinline__ void lds_wait(float4_t& a, float4_t& b, float4_t& c, float4_t& d) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); }
 __device__ __forceinline__ void lds_wait(float& a, float& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
+
+// sum over the four 16-lane rows of a wave (lanes that differ in bits 4 and 5), result in every lane, on the VALU only: v_permlane16_swap pairs rows
+// (0,1) and (2,3), v_permlane32_swap the two halves — a __shfl_xor (ds_bpermute) costs an LDS round trip per step, and a slot runs these on its
+// critical path
+__device__ __forceinline__ float sum_rows4(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+  const unsigned x = __builtin_bit_cast(unsigned, w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
@@ -127,7 +147,8 @@ struct TileId { int m0, n0; };
 // SWAP (KV kind only): this block walks V-half tiles (columns >= N/2) and runs its MFMAs with the operands exchanged.  `tiles_n`, `total_tiles`
 // count the tiles of ONE role (KV: one half of the columns); `nroles` = 2 for the KV kind: blocks with ((blockIdx.x >> 3) & 1) == 1 are the V role.
 template <typename T16, int KIND, int ACT, bool SWAP>
-__device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int nroles) {
+__device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int nroles,
+                                        const int abl) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // group (row half), column quarter
@@ -137,7 +158,9 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   // ---- persistent tile walk: block b = (XCD x = b & 7, slot s = b >> 3) takes entries s, s + S, s + 2S, ... of XCD x's contiguous band of the tile
   //      order (the order itself — super-rows of GM m-tiles, n-major inside — is gemm_pp256d_kernel's), so the S blocks of an XCD work on neighbouring tiles
   const int G = gridDim.x / nroles;                                  // blocks of this role
-  const int bx = nroles == 2 ? (int)(((blockIdx.x >> 4) << 3) | (blockIdx.x & 7)) : (int)blockIdx.x;      // this block's index among them (XCD bits kept)
+  // this block's index among them: blockIdx.x with the role bit (bit rb >= 3, the XCD bits stay) squeezed out
+  const int rb = (abl >> 8) & 15;
+  const int bx = nroles == 2 ? (int)(((blockIdx.x >> (rb + 1)) << rb) | (blockIdx.x & ((1u << rb) - 1))) : (int)blockIdx.x;
   const int n_base = SWAP ? (p.N >> 1) : 0;
   const bool banded = (G & 7) == 0;
   const int S = banded ? (G >> 3) : G;
@@ -146,6 +169,10 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   const int bandn = min(band, total_tiles - band0);                 // may be <= 0 for the last XCDs of a tiny grid
   int idx = banded ? (bx >> 3) : bx;
   if (idx >= bandn) return;
+#ifdef VLATOUCH_BENCH_BUILD      // 2 = only the K-role blocks run, 4 = only the V-role blocks (KV kind: how long does each role take alone?)
+  if ((abl & 2) && SWAP) return;
+  if ((abl & 4) && !SWAP && nroles == 2) return;
+#endif
   auto decode = [&](int id) __attribute__((always_inline)) -> TileId {
     const int sr = id / (GM * tiles_n);
     const int gmr = min(GM, tiles_m - sr * GM);
@@ -240,12 +267,10 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
           q = fmaf(x[0], x[0], q); q = fmaf(x[1], x[1], q); q = fmaf(x[2], x[2], q); q = fmaf(x[3], x[3], q);
           if (p.hn_mode == 2) sm += (x[0] + x[1]) + (x[2] + x[3]);
         });
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = sum_rows4(q);
         float var;
         if (p.hn_mode == 2) {
-          sm += __shfl_xor(sm, 16, 64);
-          sm += __shfl_xor(sm, 32, 64);
+          sm = sum_rows4(sm);
           const float mean = sm * (1.f / 64.f);
           var = (q - 64.f * mean * mean) * (1.f / 63.f);
         } else var = q * (1.f / 64.f);
@@ -290,7 +315,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
           const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
           const int m = mrow0 + j * 16 + fl15;
           const int off = lb + ((j >> 2) * 16384 + (j & 3) * 2048 + IB * 32);
-          __builtin_amdgcn_raw_buffer_store_b128((uint4_t){s0[0], s1[0], s0[1], s1[1]}, rc, m < p.M ? off : 0x7ffffff0, 0, 0);
+          pt_store((uint4_t){s0[0], s1[0], s0[1], s1[1]}, rc, m < p.M ? off : 0x7ffffff0, abl);
         });
       } else {
         // V half (swapped operands): lane = d row i*16 + l15, keys j*16 + g*4 + r; Vt position of key kk: vt_kpos -> (j&2)*16 + g*8 + (j&1)*4 + r,
@@ -318,8 +343,8 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
             const int off = lb + ((j >> 2) * 16384 + 8192 + i * 2048 + (j & 2) * 32);
             // a row block past the last tile of the stream (the second of the two tiles when only one is left) must not be written: the range
             // check covers voffset only up to num_records, which is per WAVE here -> send it out of range by hand
-            __builtin_amdgcn_raw_buffer_store_b128((uint4_t){pack16<T16>(lo[0], lo[1]), pack16<T16>(lo[2], lo[3]), pack16<T16>(hi[0], hi[1]), pack16<T16>(hi[2], hi[3])},
-                                                   rc, (mg + j * 16) < p.cmap_T * 64 ? off : 0x7ffffff0, 0, 0);
+            pt_store((uint4_t){pack16<T16>(lo[0], lo[1]), pack16<T16>(lo[2], lo[3]), pack16<T16>(hi[0], hi[1]), pack16<T16>(hi[2], hi[3])},
+                     rc, (mg + j * 16) < p.cmap_T * 64 ? off : 0x7ffffff0, abl);
           });
         });
       }
@@ -350,7 +375,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
         const auto s0 = __builtin_amdgcn_permlane16_swap(d[0][0], d[1][0], false, false);
         const auto s1 = __builtin_amdgcn_permlane16_swap(d[0][1], d[1][1], false, false);
         const int off = lb + j * 16 * rowb + IB * 32;                            // rows >= M land past num_records: dropped by the range check
-        __builtin_amdgcn_raw_buffer_store_b128((uint4_t){s0[0], s1[0], s0[1], s1[1]}, rc, off, 0, 0);
+        pt_store((uint4_t){s0[0], s1[0], s0[1], s1[1]}, rc, off, abl);
       });
     }
   };
@@ -359,6 +384,9 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   using I4 = std::integral_constant<int, 4>;
   auto slot_run = [&](auto s_tag) __attribute__((always_inline)) {
     constexpr int SL = decltype(s_tag)::value;
+#ifdef VLATOUCH_BENCH_BUILD      // timing-only ablations (tools/gemm_bench_pt.py --abl; garbage results): 1 = no epilogue slots at all
+    if (abl & 1) return;
+#endif
     if constexpr (SL == 0) epi_stats(I0{}, rstd[0]);
     else if constexpr (SL == 1) epi_store(I0{}, I0{}, rstd[0]);       // (A0, B0)
     else if constexpr (SL == 2) epi_stats(I4{}, rstd[1]);
@@ -397,14 +425,30 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
     // of this phase and, in SWITCH phase 2, the move of the staging context to the next tile
     auto head = [&](auto ph_tag) __attribute__((always_inline)) {
       constexpr int ph = decltype(ph_tag)::value;
+#ifdef VLATOUCH_PT_SLOT_HEAD      // A/B: the first placement of the slots (head of the phase, before its fragment reads)
       if constexpr (MODE == MODE_LAST && ph == 2) slot_run(std::integral_constant<int, 0>{});
       if constexpr (MODE == MODE_LAST && ph == 3) slot_run(std::integral_constant<int, 1>{});
       if constexpr (MODE == MODE_FIRST) slot_run(std::integral_constant<int, 2 + ph>{});
+#endif
       if constexpr (MODE == MODE_SWITCH && ph == 2) {           // from here on the stream belongs to the next tile (or, past the last one, re-reads this one)
         set_stage_ctx(nxt);
         stage_params(nxt, (tseq + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
+    };
+    // tail of a phase = right behind its 16 MFMAs, before the barrier that ends the compute half: the epilogue slot that the FIRST placement ran at the
+    // head of the NEXT phase.  Same position in the wave's vector-memory queue (after this phase's unit, before the next one: the wait table is
+    // unchanged) and the same live fragments, but the phase's own fragment reads were issued long ago and the slot's VALU starts while the cluster's last
+    // MFMAs still execute.  At the head the slot sat between the other group's MFMA cluster and this group's fragment reads, so every slot phase
+    // cost slot + exposed LDS latency, twice (once per group): measured 8 % of the K|V projection for the arithmetic alone (tools/pt_abl.sh).
+    auto tail = [&](auto ph_tag) __attribute__((always_inline)) {
+      constexpr int ph = decltype(ph_tag)::value;
+#ifndef VLATOUCH_PT_SLOT_HEAD
+      if constexpr (MODE == MODE_LAST && ph == 1) slot_run(std::integral_constant<int, 0>{});
+      if constexpr (MODE == MODE_LAST && ph == 2) slot_run(std::integral_constant<int, 1>{});
+      if constexpr (MODE == MODE_LAST && ph == 3) slot_run(std::integral_constant<int, 2>{});
+      if constexpr (MODE == MODE_FIRST && ph < 3) slot_run(std::integral_constant<int, 3 + ph>{});
+#endif
     };
     auto mem_end = [&](auto ph_tag) __attribute__((always_inline)) {
       constexpr int ph = decltype(ph_tag)::value;
@@ -431,6 +475,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
       }                                                                                                                    \
     });                                                                                                                    \
     __builtin_amdgcn_s_setprio(0);                                                                                         \
+    tail(std::integral_constant<int, (ah) == 0 ? (bh) : 3 - (bh)>{});      /* (A0,B0) (A0,B1) (A1,B1) (A1,B0) = phases 0 1 2 3 */ \
     __builtin_amdgcn_sched_barrier(0);                                                                                     \
     __builtin_amdgcn_s_barrier();                                                                                          \
     __builtin_amdgcn_sched_barrier(0);
@@ -490,7 +535,9 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();       // pay back the stagger
   // the last tile's remaining slots, back to back; then drain the (never consumed) trailing units before the wave ends
+#ifdef VLATOUCH_PT_SLOT_HEAD
   slot_run(std::integral_constant<int, 2>{});
+#endif
   slot_run(std::integral_constant<int, 3>{});
   slot_run(std::integral_constant<int, 4>{});
   slot_run(std::integral_constant<int, 5>{});
@@ -501,17 +548,18 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
 // V half runs its MFMAs with exchanged operands and that choice has to be compile time for the register allocator: the same 16 (of 32) blocks of an
 // XCD walk the same band of m-tiles in both roles, so the A panel they stream is shared in that XCD's L2.
 template <typename T16, int KIND, int ACT>
-__global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, const int tiles_n, const int tiles_m, const int total_tiles, const int GM) {
+__global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int abl) {
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   if constexpr (KIND == KIND_KV) {
-    if ((blockIdx.x >> 3) & 1) pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2);
-    else pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2);
+    if ((blockIdx.x >> ((abl >> 8) & 15)) & 1) pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
+    else pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
   } else {
-    pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1);
+    pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1, abl);
   }
 }
 
 int g_pt_on = -1;
+int g_pt_abl = 0;                // bench builds only (VLATOUCH_PT_ABL): see the #ifdef VLATOUCH_BENCH_BUILD blocks above
 int g_pt_cus = 0;
 
 }  // namespace
@@ -545,15 +593,22 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   const int gm = g_vt_gm > 0 ? g_vt_gm : 8;
   int grid;
   if (kv) {                                            // two roles: a multiple of 16 blocks, each role at most `total` blocks
-    grid = 2 * total < g_pt_cus ? 2 * total : g_pt_cus;
-    grid &= ~15;
-    if (grid < 16) return VT_ERR_UNSUPPORTED;
+    static const int kv_grid = [] { const char* e = getenv("VLATOUCH_PT_KV_GRID"); return e ? atoi(e) : 0; }();   // A/B: leave CUs to a co-running stream
+    const int cap = kv_grid > 0 && kv_grid < g_pt_cus ? kv_grid : g_pt_cus;
+    grid = 2 * total < cap ? 2 * total : cap;
+    grid &= ~255;                                      // (role bit up to 7: whole groups of 256 blocks)
+    if (grid < 256) return VT_ERR_UNSUPPORTED;
   } else {
     grid = total < g_pt_cus ? total : g_pt_cus;
     if (grid >= 8) grid &= ~7;
   }
   VtProfScope prof(2, p, s);
-#define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm)
+#ifdef VLATOUCH_BENCH_BUILD
+  { const char* e = getenv("VLATOUCH_PT_ABL"); g_pt_abl = e ? atoi(e) : 0; }
+#endif
+  // bits 8..11 of the last argument: which bit of blockIdx.x selects the role of a KV-kind block (3 .. 7; VLATOUCH_PT_ROLE_BIT for A/B)
+  static const int role_bit = [] { const char* e = getenv("VLATOUCH_PT_ROLE_BIT"); const int v = e ? atoi(e) : 3; return v >= 3 && v <= 7 ? v : 3; }();
+#define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8))
   if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
   else if (p.a_dtype == VT_BF16) {
     if (p.act == VT_ACT_NONE) VT_PT_GO(bf16_t, KIND_P16, VT_ACT_NONE);
