@@ -140,3 +140,41 @@ def test_persistent_tile_fused_kv_projection(dev, M, K, mode):
     assert float((vn[:, :M].float() - vr[:, :M]).abs().max() / vr.abs().max()) < 1e-2
     again, _ = both(run2)
     assert torch.equal(new, again)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,inplace", [
+    (139968 // 2, 1152, 1152, True),      # SigLIP out-projection shape (half the batch): 4.5 n-tiles, 5 tiles per block, residual stream updated in place
+    (16384, 768, 3072, False),            # DINOv2-B fc2: 192 tiles, one per block (flat epilogue only), separate output
+    (40000, 768, 768, True),              # ragged M, 3 n-tiles, nk = 12
+    (33000, 2048, 576, False),            # nk = 9 (buffer parity flips per tile)
+])
+def test_persistent_tile_fp32_residual_kind(dev, dtype, M, N, K, inplace):
+    """R32 kind: C (fp32) = residual + colscale * (A W^T + bias) — the LayerScale + residual epilogue of the ViT out-projection / fc2 — against
+    gemm_pp256d_kernel on the same launch and a torch fp32 reference."""
+    from vlatouch import ops
+    a = rnd((M, K), 1, dev, dtype)
+    w = rnd((N, K), 2, dev, dtype, K ** -0.5)
+    bias = rnd((N,), 3, dev)
+    cs = rnd((N,), 4, dev) * 0.3 + 1.0
+    res0 = rnd((M + 2, N), 5, dev)                                        # 2 guard rows
+    buf = torch.empty_like(res0)
+
+    def run():
+        buf.copy_(res0)
+        if inplace:
+            ops.gemm(a, w, bias, colscale=cs, residual=buf[:M], out=buf[:M], out_dtype=torch.float32)
+            return buf.clone()
+        out = torch.full((M + 2, N), 7.0, device=dev)
+        ops.gemm(a, w, bias, colscale=cs, residual=buf[:M], out=out[:M], out_dtype=torch.float32)
+        return torch.cat([out, buf])
+    new, old = both(run)
+    guard = res0[M:] if inplace else torch.full((2, N), 7.0, device=dev)
+    assert torch.equal(new[M:M + 2], guard)                               # nothing written past row M
+    scale = float(old[:M].abs().max())
+    assert float((new - old).abs().max()) <= 2e-6 * scale                 # same arithmetic (the compiler may contract mul + add differently)
+    ref = res0[:M] + cs * (a.float() @ w.float().t() + bias)
+    err = float((new[:M] - ref).abs().max() / ref.abs().max())
+    assert err < (1e-2 if dtype == torch.bfloat16 else 2e-3), err
+    again, _ = both(run)
+    assert torch.equal(new, again)

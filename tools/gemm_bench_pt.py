@@ -23,11 +23,15 @@ def timeit(fn, n):
     return e0.elapsed_time(e1) / n
 
 
-def case(name, M, N, K, dt, act=L.ACT_NONE, kv=False):
+def case(name, M, N, K, dt, act=L.ACT_NONE, kv=False, r32=False):
     a = torch.randn(M, K, device=dev).to(dt)
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     bias = torch.randn(N, device=dev)
-    if kv:
+    if r32:
+        res = torch.randn(M, N, device=dev)
+        cs = torch.ones(N, device=dev)
+        fn = lambda: ops.gemm(a, w, bias, colscale=cs, residual=res, out=res, out_dtype=torch.float32)
+    elif kv:
         T = (M + 63) // 64
         out = torch.empty(N // 128, T, 2, 64, 64, device=dev, dtype=dt)
         gain = torch.ones(64, device=dev)
@@ -55,4 +59,7 @@ case("dinov2-b qkv", 16384, 2304, 768, h)
 case("dinov2-b fc1 gelu", 16384, 3072, 768, h, act=L.ACT_GELU_ERF)
 case("siglip qkv", 139968, 3456, 1152, h)
 case("siglip fc1 gelu", 139968, 4304, 1152, h, act=L.ACT_GELU_TANH)
+case("siglip out-proj (fp32+res)", 139968, 1152, 1152, h, r32=True)
+case("siglip fc2 (fp32+res)", 139968, 1152, 4352, h, r32=True)
+case("dinov2-b fc2 (fp32+res)", 16384, 768, 3072, h, r32=True)
 case("square 8192", 8192, 8192, 8192, bf)

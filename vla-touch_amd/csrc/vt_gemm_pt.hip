@@ -48,12 +48,12 @@ typedef __attribute__((ext_vector_type(2))) unsigned uint2_t;
 
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int BUF_BYTES = (BM + BN) * 128;        // one k-tile: A rows 0..255 then B rows 0..255, 128 B each
-constexpr int PAR_OFF = 2 * BUF_BYTES;            // parameter area: [slot 2][wave 8][64 floats] bias of the wave's 64 columns
-constexpr int PAR_WAVE = 256;
+constexpr int PAR_OFF = 2 * BUF_BYTES;            // parameter area: [slot 2][wave 8][64 floats bias | 64 floats column scale] of the wave's 64 columns
+constexpr int PAR_WAVE = 512;
 constexpr int HN_OFF = PAR_OFF + 2 * 8 * PAR_WAVE;   // 64 floats: head-norm gains (k_norm) of the KV kind
 constexpr int SMEM_BYTES = HN_OFF + 256;
 
-enum { KIND_KV = 0, KIND_P16 = 1 };
+enum { KIND_KV = 0, KIND_P16 = 1, KIND_R32 = 2 };
 enum { MODE_STEADY = 0, MODE_FIRST = 1, MODE_SECOND = 2, MODE_SWITCH = 3, MODE_LAST = 4 };
 
 // the epilogue's store; bench builds can turn it into a register sink (VLATOUCH_PT_ABL & 8: what do the stores themselves cost?)
@@ -119,12 +119,16 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 //                                AFTER the piece); ph 3 = phase F-1: + S1's 4 stores (issued this phase, before the stage)
 //   FIRST  (next tile, k-tile 0) phases F..F+3: store slots among P-3..P: {F-1} / {F-1,F+1} / {F-1,F+1,F+2} / {F+1,F+2,F+3} -> 12 / 16 / 20 / 20
 //   SECOND (k-tile 1)            phases F+4..F+7: {F+1,F+2,F+3} / {F+2,F+3} / {F+3} / {} -> 20 / 16 / 12 / 8
-__host__ __device__ constexpr int wait_count(int mode, int ph) {
-  return mode == MODE_SWITCH ? (ph < 2 ? 8 : 9)
-       : mode == MODE_LAST   ? (ph < 2 ? 9 : (ph == 2 ? 8 : 12))
-       : mode == MODE_FIRST  ? (ph == 0 ? 12 : (ph == 1 ? 16 : 20))
-       : mode == MODE_SECOND ? (ph == 0 ? 20 : (ph == 1 ? 16 : (ph == 2 ? 12 : 8)))
-       : 8;
+//   R32 kind: TWO parameter pieces per tile (bias, column scale) and no store slots; its 32 stores per wave are issued in one flat block between the
+//   last phase of a tile and phase F of the next: every FIRST phase's target unit (F+2 .. F+5) was staged BEFORE them -> 8 + 32 = 40; SECOND: 8.
+__host__ __device__ constexpr int wait_count(int kind, int mode, int ph) {
+  return kind == KIND_R32
+       ? (mode == MODE_SWITCH ? (ph < 2 ? 8 : 10) : mode == MODE_LAST ? (ph < 2 ? 10 : 8) : mode == MODE_FIRST ? 40 : 8)
+       : (mode == MODE_SWITCH ? (ph < 2 ? 8 : 9)
+        : mode == MODE_LAST   ? (ph < 2 ? 9 : (ph == 2 ? 8 : 12))
+        : mode == MODE_FIRST  ? (ph == 0 ? 12 : (ph == 1 ? 16 : 20))
+        : mode == MODE_SECOND ? (ph == 0 ? 20 : (ph == 1 ? 16 : (ph == 2 ? 12 : 8)))
+        : 8);
 }
 
 template <typename T16> __device__ __forceinline__ unsigned pack16(float a, float b);
@@ -226,6 +230,10 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
     const int n = min(t.n0 + wn * 64 + lane, p.N - 1);
     const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)bias, 0, 0x7fffffff, 0x00020000);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void*)(smem + PAR_OFF + (slot * 8 + wave) * PAR_WAVE), 4, n * 4, 0, 0, 0);
+    if constexpr (KIND == KIND_R32) {
+      const __amdgpu_buffer_rsrc_t rcs = __builtin_amdgcn_make_buffer_rsrc((void*)p.colscale, 0, 0x7fffffff, 0x00020000);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rcs, (lds_void*)(smem + PAR_OFF + (slot * 8 + wave) * PAR_WAVE + 256), 4, n * 4, 0, 0, 0);
+    }
   };
 
   float4_t acc[4][8];
@@ -382,8 +390,54 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   using I0 = std::integral_constant<int, 0>;
   using I2 = std::integral_constant<int, 2>;
   using I4 = std::integral_constant<int, 4>;
+  // R32 kind: C (fp32) = residual + colscale * (acc + bias), the whole 128 x 64 sub-tile of the wave in one flat block at the end of the tile, two
+  // quadrants at a time: 16 residual loads (64 registers: the fragments are dead here) in flight, then their arithmetic and 16 stores.  The residual
+  // loads are ordinary VGPR loads, so hipcc drains the wave's queue at their first use — the next tile's first six units are in flight by then and
+  // are needed next anyway.  (Folded into the next tile's k-loop like the 16-bit kinds, the loads would need 32 more registers than the wave
+  // has, or a counted wait that keeps only ONE operand unit in flight for four phases.)
+  auto epi_flat = [&]() __attribute__((always_inline)) {
+    if constexpr (KIND == KIND_R32) {
+      const int mrow0 = et.m0 + wm * 128, ncol0 = et.n0 + wn * 64;
+      const int fl = fresh_lane(), fg = fl >> 4, fl15 = fl & 15;
+      const unsigned pa = smem_base + PAR_OFF + (eslot * 8 + wave) * PAR_WAVE + fg * 16;
+      float4_t b4[4], c4[4];
+      b4[0] = lds_ld128<0>(pa); b4[1] = lds_ld128<64>(pa); b4[2] = lds_ld128<128>(pa); b4[3] = lds_ld128<192>(pa);
+      c4[0] = lds_ld128<256>(pa); c4[1] = lds_ld128<320>(pa); c4[2] = lds_ld128<384>(pa); c4[3] = lds_ld128<448>(pa);
+      lds_wait(b4[0], b4[1], b4[2], b4[3]);
+      lds_wait(c4[0], c4[1], c4[2], c4[3]);
+      const long rows_left = (long)p.M - mrow0;
+      const bool ok = rows_left > 0 && ncol0 < p.N;
+      const long nrows = rows_left < 128 ? rows_left : 128;
+      char* cbase = reinterpret_cast<char*>(p.C) + ((long)mrow0 * p.ldc + ncol0) * 4;
+      const char* rbase = reinterpret_cast<const char*>(p.residual) + ((long)mrow0 * p.ldr + ncol0) * 4;
+      const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)cbase, 0, ok ? (int)((nrows - 1) * p.ldc * 4 + 256) : 0, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)rbase, 0, ok ? (int)((nrows - 1) * p.ldr * 4 + 256) : 0, 0x00020000);
+      const int crow = (int)p.ldc * 4, rrow = (int)p.ldr * 4;
+      const int clane = fl15 * crow + fg * 16, rlane = fl15 * rrow + fg * 16;
+      static_for<0, 2>([&](auto h_) __attribute__((always_inline)) {          // rows 0..63, then rows 64..127 of the wave
+        constexpr int JB = decltype(h_)::value * 4;
+        uint4_t rv[4][4];
+        static_for<0, 4>([&](auto jj_) __attribute__((always_inline)) {
+          static_for<0, 4>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int jj = decltype(jj_)::value, i = decltype(i_)::value, j = JB + jj;
+            rv[jj][i] = __builtin_amdgcn_raw_buffer_load_b128(rr, rlane + j * 16 * rrow + i * 64, 0, 0);
+          });
+        });
+        static_for<0, 4>([&](auto jj_) __attribute__((always_inline)) {
+          static_for<0, 4>([&](auto i_) __attribute__((always_inline)) {
+            constexpr int jj = decltype(jj_)::value, i = decltype(i_)::value, j = JB + jj;
+            float4_t x = acc[i][j];
+            const float4_t r = __builtin_bit_cast(float4_t, rv[jj][i]);
+            x = (x + b4[i]) * c4[i] + r;
+            pt_store(__builtin_bit_cast(uint4_t, x), rc, clane + j * 16 * crow + i * 64, abl);
+          });
+        });
+      });
+    }
+  };
   auto slot_run = [&](auto s_tag) __attribute__((always_inline)) {
     constexpr int SL = decltype(s_tag)::value;
+    if constexpr (KIND == KIND_R32) return;
 #ifdef VLATOUCH_BENCH_BUILD      // timing-only ablations (tools/gemm_bench_pt.py --abl; garbage results): 1 = no epilogue slots at all
     if (abl & 1) return;
 #endif
@@ -404,7 +458,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   stage_params(cur, 0);
 #pragma unroll
   for (int n = 0; n < 6; ++n) stage(n & 3, (n >> 2) & 1, n >> 2);          // nk >= 4: units 0..5 exist
-  wait_vm<8>();                                                             // the parameter piece and units 0, 1 landed
+  wait_vm<8>();                                                             // the parameter piece(s) and units 0, 1 landed
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // wave 0's gain row (a __syncthreads() here would drain the DMA queue)
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();       // stagger group 1 by one barrier (group 0 pays it back after the loop)
@@ -457,7 +511,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
       if constexpr (MODE == MODE_SWITCH) { if (ph >= 2) ks = 0; }
       if constexpr (MODE == MODE_LAST) ks = ph < 2 ? 0 : 1;
       stage(U, (kt + DT + par) & 1, ks);
-      wait_vm<wait_count(MODE, ph)>();
+      wait_vm<wait_count(KIND, MODE, ph)>();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
@@ -529,6 +583,7 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
     ktile(nk - 2, std::integral_constant<int, MODE_SWITCH>{});
     et = cur; eslot = tseq & 1;                      // slots S0 .. S5 finish THIS tile (S2 .. S5 inside the next tile's first k-tile)
     ktile(nk - 1, std::integral_constant<int, MODE_LAST>{});
+    epi_flat();                                      // R32 kind only
     if (!has_next) break;
     cur = nxt; idx = nidx; ++tseq;
     par ^= (nk & 1);
@@ -574,7 +629,10 @@ void vt_gemm_pt_tune(int value) {
 bool vt_gemm_pt_eligible(const VtGemmParams& p) {
   if (g_pt_on < 0) { const char* e = getenv("VLATOUCH_PT"); g_pt_on = e ? atoi(e) : 1; }
   if (!g_pt_on || !vt_gemm_pp_eligible(p)) return false;
-  if (p.groups != 1 || p.K < 4 * BK || p.residual || p.colscale || !p.bias || p.c_dtype == VT_F32 || (p.N % 64)) return false;
+  if (p.groups != 1 || p.K < 4 * BK || !p.bias || (p.N % 64)) return false;
+  if (p.c_dtype == VT_F32)          // R32 kind: fp32 C = residual + colscale * (acc + bias)
+    return p.residual && p.colscale && p.cmap == 0 && !p.hn_w0 && !p.hn_w1 && p.act == VT_ACT_NONE && (long)p.ldc * 4 * 128 < (1L << 31) && (long)p.ldr * 4 * 128 < (1L << 31);
+  if (p.residual || p.colscale) return false;
   if (p.cmap == 3) return p.a_dtype == VT_BF16 && (p.N % 512) == 0 && p.hn_c0_end == (p.N >> 1) && !p.hn_w1 && p.act == VT_ACT_NONE && p.hn_w0;
   if (p.cmap != 0 || p.hn_w0 || p.hn_w1) return false;
   if ((long)p.ldc * 2 * 128 >= (1L << 31)) return false;
@@ -610,6 +668,7 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   static const int role_bit = [] { const char* e = getenv("VLATOUCH_PT_ROLE_BIT"); const int v = e ? atoi(e) : 3; return v >= 3 && v <= 7 ? v : 3; }();
 #define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8))
   if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
+  else if (p.c_dtype == VT_F32) { if (p.a_dtype == VT_BF16) VT_PT_GO(bf16_t, KIND_R32, VT_ACT_NONE); else VT_PT_GO(half_t, KIND_R32, VT_ACT_NONE); }
   else if (p.a_dtype == VT_BF16) {
     if (p.act == VT_ACT_NONE) VT_PT_GO(bf16_t, KIND_P16, VT_ACT_NONE);
     else if (p.act == VT_ACT_GELU_ERF) VT_PT_GO(bf16_t, KIND_P16, VT_ACT_GELU_ERF);
