@@ -28,9 +28,9 @@ def case(name, M, N, K, dt, act=L.ACT_NONE, kv=False, r32=False):
     w = (torch.randn(N, K, device=dev) * K ** -0.5).to(dt)
     bias = torch.randn(N, device=dev)
     if r32:
-        res = torch.randn(M, N, device=dev)
+        resid = torch.randn(M, N, device=dev)
         cs = torch.ones(N, device=dev)
-        fn = lambda: ops.gemm(a, w, bias, colscale=cs, residual=res, out=res, out_dtype=torch.float32)
+        fn = lambda: ops.gemm(a, w, bias, colscale=cs, residual=resid, out=resid, out_dtype=torch.float32)
     elif kv:
         T = (M + 63) // 64
         out = torch.empty(N // 128, T, 2, 64, 64, device=dev, dtype=dt)

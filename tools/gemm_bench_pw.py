@@ -168,7 +168,7 @@ if __name__ == "__main__":
         wps = [ops.pack_w32(w) for w in ws_]
         out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
         lib.vt_tune(2, 1); lib.vt_tune(1, 4)
-        for k, name in ((0, "full kernel"), (1, "no fragment reads"), (2, "no weight loads"), (3, "no MFMAs"), (4, "no activation DMA")):
+        for k, name in ((0, "full kernel"), (1, "no fragment reads"), (2, "no weight loads"), (3, "no MFMAs"), (4, "no activation DMA"), (5, "no epilogue")):
             lib.vt_tune(5, k)
             t = graph_time(lambda i: ops.gemm(a, ws_[i % NW], out=out, out_dtype=torch.bfloat16, wp=wps[i % NW]), NW)
             print(f"  ablation {k} ({name:18s}): {t:6.2f} us", flush=True)

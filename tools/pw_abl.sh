@@ -1,0 +1,10 @@
+#!/bin/bash
+# Timing-only ablations of the weights-in-registers tile (bench build; garbage results): tools/gemm_bench_pw.py --abl
+cd $GRAFT_REPO_ROOT/vla-touch_amd/csrc
+rm -rf build_bench; mkdir -p build_bench
+for f in *.hip; do o=build_bench/${f%.hip}.o; e=""; [ $f = vt_uconv.hip ] && e="-Xclang -target-feature -Xclang -packed-fp32-ops"; /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -DVLATOUCH_BENCH_BUILD $e -c $f -o $o 2>/dev/null & done; wait
+cp ../vlatouch/libvlatouch_hip.so /tmp/libvlatouch_hip.product.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vlatouch/libvlatouch_hip.so build_bench/*.o
+cd $GRAFT_REPO_ROOT
+python tools/gemm_bench_pw.py --abl 2>&1 | grep -i "ablation"
+cp /tmp/libvlatouch_hip.product.so vla-touch_amd/vlatouch/libvlatouch_hip.so

@@ -190,6 +190,11 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   for (; t + NB < nk; t += NB) static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::false_type{}); });
   static_for<NB>([&](auto uc) { sub(t + decltype(uc)::value, uc, std::true_type{}); });
 
+  if constexpr (ABL == 5) {      // timing only: no epilogue (the accumulators are kept alive, nothing is stored)
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) asm volatile("" :: "v"(acc[j]));
+    return;
+  }
   // ---------------- epilogue: accumulators -> the block's fp32 tile in LDS [160][128], 16-byte columns XOR-swizzled by the row; read back as
   // row segments: 16 lanes cover 64 columns (= one head) of one row, 4 rows per instruction; wave w takes column half w & 1 of rows (w >> 1) * 80 ..
   float* tile = reinterpret_cast<float*>(smem);
@@ -302,7 +307,8 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
     if (g_vt_pw_abl == 1) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 1>), g, b, 0, s, p, tiles_n, per_group, total, gm);
     else if (g_vt_pw_abl == 2) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 2>), g, b, 0, s, p, tiles_n, per_group, total, gm);
     else if (g_vt_pw_abl == 3) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 3>), g, b, 0, s, p, tiles_n, per_group, total, gm);
-    else hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 4>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    else if (g_vt_pw_abl == 4) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 4>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    else hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 5>), g, b, 0, s, p, tiles_n, per_group, total, gm);
     return vt_check_launch();
   }
 #endif
@@ -320,7 +326,7 @@ extern "C" int vt_tune(int knob, int value) {
   if (knob == 1 && (value == 0 || value == 4 || value == 8)) { g_vt_pw_nb = value; return VT_OK; }
   if (knob == 2) { g_vt_pw_on = value != 0; return VT_OK; }
 #ifdef VLATOUCH_BENCH_BUILD
-  if (knob == 5 && value >= 0 && value <= 4) { g_vt_pw_abl = value; return VT_OK; }
+  if (knob == 5 && value >= 0 && value <= 5) { g_vt_pw_abl = value; return VT_OK; }
 #else
   if (knob == 5) return value == 0 ? VT_OK : vt_fail(VT_ERR_UNSUPPORTED, "vt_tune(5, .): the timing-only ablations exist only in a bench build (make DEFS=-DVLATOUCH_BENCH_BUILD)");
 #endif
