@@ -233,6 +233,18 @@ def test_dino_cls_golden(dev, dino_engines, prec):
 
 
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
+def test_dino_large_golden(dev, prec):
+    """dinov2-large against the reference's own output (g3_dino_large: 24 layers x 1024, 16 heads): the third size DINOv2Encoder offers; both input
+    branches (bright -> ImageNet normalisation, dark -> none).  Twice the depth of the other sizes: the 16-bit tolerances are the same."""
+    from vlatouch.engine import DinoEngine
+    g = G("g3_dino_large")
+    eng = DinoEngine(cases.dino_sd("large"), heads=16, precision=prec, device=dev)
+    for kind in ("bright", "dark"):
+        out = eng.forward([cases.frames(2, 224, kind)], nhwc=False)[0]
+        assert max_err(out, g[f"large_224_{kind}"]) < DINO_TOL[prec], (prec, kind, max_err(out, g[f"large_224_{kind}"]))
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_dino_base_golden_and_two_cameras(dev, dino_engines, prec):
     g = G("g3_dino_cls")
     eng = dino_engines[("base", prec)]

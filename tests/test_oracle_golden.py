@@ -92,6 +92,15 @@ def test_g3_dino_cls():
     close(od.encode(cases.dino_sd("base"), cases.frames(2, 224, "bright"), 12), g["base_224_bright"], 3e-5, "base")
 
 
+def test_g3_dino_large():
+    """dinov2-large (hidden 1024, 24 layers, 16 heads: a size the reference's DINOv2Encoder offers, visual_encoder.py:31-46) — fixture from the
+    reference class itself (tools/make_golden_dino_large.py)."""
+    g = G("g3_dino_large")
+    sd = cases.dino_sd("large")
+    for kind in ("bright", "dark"):
+        close(od.encode(sd, cases.frames(2, 224, kind), 16), g[f"large_224_{kind}"], 5e-5, kind)
+
+
 def test_g5_predict_end_to_end():
     g = G("g5_predict_e2e")
     inp = cases.predict_inputs(2, 16, 224)

@@ -7,5 +7,5 @@ for f in *.hip; do o=build_bench/${f%.hip}.o; e=""; [ $f = vt_uconv.hip ] && e="
 cp ../vlatouch/libvlatouch_hip.so /tmp/libvlatouch_hip.product.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../vlatouch/libvlatouch_hip.so build_bench/*.o
 cd $GRAFT_REPO_ROOT
-for a in 0 1 8; do echo "== VLATOUCH_PT_ABL=$a"; VLATOUCH_PT_ABL=$a python tools/gemm_bench_pt.py kv 2>&1 | grep "K|V"; done
+for a in 0 16 32 64 0; do echo "== VLATOUCH_PT_ABL=$a"; VLATOUCH_PT_ABL=$a python tools/gemm_bench_pt.py kv 2>&1 | grep "K|V"; done
 cp /tmp/libvlatouch_hip.product.so vla-touch_amd/vlatouch/libvlatouch_hip.so

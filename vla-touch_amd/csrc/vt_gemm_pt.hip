@@ -61,6 +61,11 @@ __device__ __forceinline__ void pt_store(const uint4_t d, const __amdgpu_buffer_
 #ifdef VLATOUCH_BENCH_BUILD
   if (abl & 8) { asm volatile("" :: "v"(d), "v"(off)); return; }
 #endif
+#ifdef VLATOUCH_BENCH_BUILD      // A/B of the store's cache policy bits (VLATOUCH_PT_ABL bits 4..6 -> aux: 1 = sc0, 2 = nt, 3 = sc0 nt)
+  if ((abl >> 4) & 1) { __builtin_amdgcn_raw_buffer_store_b128(d, rc, off, 0, 2); return; }
+  if ((abl >> 5) & 1) { __builtin_amdgcn_raw_buffer_store_b128(d, rc, off, 0, 3); return; }
+  if ((abl >> 6) & 1) { __builtin_amdgcn_raw_buffer_store_b128(d, rc, off, 0, 1); return; }
+#endif
   __builtin_amdgcn_raw_buffer_store_b128(d, rc, off, 0, 0);
 }
 
