@@ -57,6 +57,7 @@ def gelu_ref(y, act):
     (35000, 2048, 576, "tanh"),       # nk = 9: the LDS buffer parity flips from tile to tile
     (2144, 6144, 2048, "none"),       # 216 tiles on 216 blocks: one tile per block, epilogue entirely in the flat tail
     (70001, 1024, 512, "erf"),        # M % 4 == 1, 4 n-tiles, 4.3 tiles per block
+    (16448, 768, 1024, "tanh"),       # 195 tiles on 195 blocks (not a multiple of 8: plain tile order)
 ])
 def test_persistent_tile_row_major_16bit(dev, dtype, M, N, K, act):
     from vlatouch import ops, _lib as L
@@ -148,6 +149,8 @@ def test_persistent_tile_fused_kv_projection(dev, M, K, mode):
     (16384, 768, 3072, False),            # DINOv2-B fc2: 192 tiles, one per block (flat epilogue only), separate output
     (40000, 768, 768, True),              # ragged M, 3 n-tiles, nk = 12
     (33000, 2048, 576, False),            # nk = 9 (buffer parity flips per tile)
+    (16448, 768, 3072, True),             # 65 x 3 = 195 tiles: one block per tile, a grid that is not a multiple of 8 (plain tile order), ragged last m-tile
+    (16448, 768, 768, True),              # DINOv2-B out-projection: one round at K = 768, a shape only the persistent kernel takes (vt_gemm_pt_extra_shape)
 ])
 def test_persistent_tile_fp32_residual_kind(dev, dtype, M, N, K, inplace):
     """R32 kind: C (fp32) = residual + colscale * (A W^T + bias) — the LayerScale + residual epilogue of the ViT out-projection / fc2 — against

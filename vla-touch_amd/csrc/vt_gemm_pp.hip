@@ -312,7 +312,10 @@ __global__ __launch_bounds__(512, 2) void gemm_pp256d_kernel(const VtGemmParams 
 
 }  // namespace
 
-bool vt_gemm_pp_eligible(const VtGemmParams& p) {
+bool vt_gemm_pp_eligible(const VtGemmParams& p) { return vt_gemm_pp_shape(p) || vt_gemm_pt_extra_shape(p); }
+
+// the shapes gemm_pp256d_kernel is good at (the persistent kernel of vt_gemm_pt.hip takes these and a few more, vt_gemm_pt_extra_shape)
+bool vt_gemm_pp_shape(const VtGemmParams& p) {
   if (!vt_gemm_fast_eligible(p)) return false;
   const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256) * p.groups;
   if (p.lda >= (1 << 21) || p.ldw >= (1 << 21) || p.K >= (1 << 24)) return false;   // 32-bit buffer offsets inside a 256-row block

@@ -624,17 +624,11 @@ int g_pt_cus = 0;
 
 }  // namespace
 
-void vt_gemm_pt_tune(int value) {
-  VtGemmParams dummy{};
-  (void)vt_gemm_pt_eligible(dummy);          // the environment default is read before the first explicit setting
-  g_pt_on = value != 0;
-}
 
-// which launches take the persistent kernel: the shapes gemm_pp256d_kernel takes, restricted to the epilogue kinds above
-bool vt_gemm_pt_eligible(const VtGemmParams& p) {
-  if (g_pt_on < 0) { const char* e = getenv("VLATOUCH_PT"); g_pt_on = e ? atoi(e) : 1; }
-  if (!g_pt_on || !vt_gemm_pp_eligible(p)) return false;
+// epilogue kinds the persistent kernel has (anything else stays on gemm_pp256d_kernel)
+static bool pt_kind_ok(const VtGemmParams& p) {
   if (p.groups != 1 || p.K < 4 * BK || !p.bias || (p.N % 64)) return false;
+  if (p.lda >= (1 << 21) || p.ldw >= (1 << 21) || p.K >= (1 << 24)) return false;   // 32-bit buffer offsets inside a 256-row block
   if (p.c_dtype == VT_F32)          // R32 kind: fp32 C = residual + colscale * (acc + bias)
     return p.residual && p.colscale && p.cmap == 0 && !p.hn_w0 && !p.hn_w1 && p.act == VT_ACT_NONE && (long)p.ldc * 4 * 128 < (1L << 31) && (long)p.ldr * 4 * 128 < (1L << 31);
   if (p.residual || p.colscale) return false;
@@ -643,6 +637,28 @@ bool vt_gemm_pt_eligible(const VtGemmParams& p) {
   if ((long)p.ldc * 2 * 128 >= (1L << 31)) return false;
   return p.act == VT_ACT_NONE || p.act == VT_ACT_GELU_ERF || p.act == VT_ACT_GELU_TANH;
 }
+static bool pt_enabled() {
+  if (g_pt_on < 0) { const char* e = getenv("VLATOUCH_PT"); g_pt_on = e ? atoi(e) : 1; }
+  return g_pt_on != 0;
+}
+
+void vt_gemm_pt_tune(int value) {
+  (void)pt_enabled();                        // the environment default is read before the first explicit setting
+  g_pt_on = value != 0;
+}
+
+// One round of 160 .. 256 tiles at K >= 512 (DINOv2-B out-projection: 64 x 3 tiles, K = 768): too short for gemm_pp256d_kernel to beat the 128-column
+// tiles (its 64-KiB prologue fill and LDS-patch epilogue are a third of such a launch), fine for this kernel (continuous operand stream is moot with one
+// tile per block, but the in-register epilogue is not).  VLATOUCH_PT_EXTRA=0 for A/B.
+bool vt_gemm_pt_extra_shape(const VtGemmParams& p) {
+  static const bool on = [] { const char* e = getenv("VLATOUCH_PT_EXTRA"); return !e || atoi(e) != 0; }();
+  if (!on || !pt_enabled() || p.cmap != 0 || !vt_gemm_fast_eligible(p) || !pt_kind_ok(p)) return false;
+  const long tiles256 = (long)((p.M + 255) / 256) * ((p.N + 255) / 256);
+  return tiles256 >= 160 && tiles256 <= 256 && p.K >= 512;
+}
+
+// which launches take the persistent kernel
+bool vt_gemm_pt_eligible(const VtGemmParams& p) { return pt_enabled() && pt_kind_ok(p) && (vt_gemm_pp_shape(p) || vt_gemm_pt_extra_shape(p)); }
 
 int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   if (!g_pt_cus) {
@@ -662,8 +678,9 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
     grid &= ~255;                                      // (role bit up to 7: whole groups of 256 blocks)
     if (grid < 256) return VT_ERR_UNSUPPORTED;
   } else {
-    grid = total < g_pt_cus ? total : g_pt_cus;
-    if (grid >= 8) grid &= ~7;
+    // one block per tile when the tiles fit the chip (195 tiles must not become 192 blocks + a second round for 3 of them: the kernel falls back to the
+    // plain tile order when the grid is not a multiple of 8); otherwise one block per CU, XCD-banded
+    grid = total <= g_pt_cus ? total : (g_pt_cus & ~7);
   }
   VtProfScope prof(2, p, s);
 #ifdef VLATOUCH_BENCH_BUILD

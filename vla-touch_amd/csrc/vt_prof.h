@@ -43,6 +43,8 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p);
 bool vt_gemm_can_fuse_headnorm(const VtGemmParams& p);
 bool vt_gemm_pp_eligible(const VtGemmParams& p);          // vt_gemm_pp.hip: 256-square ping-pong tile
 int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s);
+bool vt_gemm_pp_shape(const VtGemmParams& p);             // what gemm_pp256d_kernel itself is eligible for
+bool vt_gemm_pt_extra_shape(const VtGemmParams& p);       // shapes only the persistent kernel takes (one round of 160 .. 256 tiles at K >= 512)
 bool vt_gemm_pt_eligible(const VtGemmParams& p);          // vt_gemm_pt.hip: the same tile, persistent, epilogue on registers inside the main loop
 int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s);
 void vt_gemm_pt_tune(int value);                           // 1 = on (default; env VLATOUCH_PT), 0 = off (gemm_pp256d_kernel takes those launches)
