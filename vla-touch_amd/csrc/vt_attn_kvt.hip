@@ -493,9 +493,12 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   // fixed-maximum softmax (see attn_kvt_ring_kernel): only with a finite load-time bound small enough that exp(-2B) stays a normal number
   attn_env_once();
   const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= 40.f;
+  // A/B: extra (unused) dynamic LDS per block lowers the blocks per CU from 4 (4 x 40 KiB = the whole CU) so that a GEMM block of the other in-flight
+  // batch can share the CU (VLATOUCH_ATTN_LDS_PAD bytes: 13000 -> 3 blocks, 40000 -> 2 blocks)
+  static const int lds_pad = [] { const char* e = getenv("VLATOUCH_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
 #define VT_KVT_GO(grid) \
-  do { if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), 0, s, p); \
-       else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false>), grid, dim3(64 * nw), 0, s, p); \
+  do { if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false>), grid, dim3(64 * nw), lds_pad, s, p); \
        else if (ring == 4) hipLaunchKernelGGL((attn_kvt_ring_kernel<4, false>), grid, dim3(64 * nw), 0, s, p); \
        else if (ring == 3) hipLaunchKernelGGL((attn_kvt_ring_kernel<3, false>), grid, dim3(64 * nw), 0, s, p); \
        else hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p); } while (0)
