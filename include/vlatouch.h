@@ -156,7 +156,8 @@ typedef struct {
   /* ViT variants beyond DINOv2 (all 0 = DINOv2): SigLIP has no CLS token, tanh-GELU, 72-wide heads packed zero-padded to 96,
    * an FFN width that is not 4*hidden, and returns every token after the final LayerNorm */
   int no_cls;        /* 1: no CLS token (tokens = patches) */
-  int act;           /* 0: erf GELU (VT_ACT_GELU_ERF); else a VT_ACT_* code */
+  int act;           /* 0: erf GELU (VT_ACT_GELU_ERF); else a VT_ACT_* code; 5 (VT_ACT_SWIGLU) = dinov2-giant's gated FFN: fc1 = weights_in
+                        [2*mlp_dim][hidden] -> silu(x1) * x2 -> fc2 = weights_out [hidden][mlp_dim] (HF Dinov2SwiGLUFFN) */
   int head_dim;      /* 0 / 64, or 96 (attention width heads*head_dim; weights packed accordingly) */
   int mlp_dim;       /* 0: 4*hidden; else the (64-padded) FFN width */
   int out_all;       /* 0: out = [ncams][B][hidden] CLS rows; 1: out = [ncams][B][tokens][hidden] */

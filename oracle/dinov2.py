@@ -76,8 +76,12 @@ def dinov2_forward(sd: SD, pixel_values: torch.Tensor, heads: int, patch: int = 
         a = F.linear(a, sd[f"{p}.attention.output.dense.weight"], sd[f"{p}.attention.output.dense.bias"])
         tok = a * sd[f"{p}.layer_scale1.lambda1"] + tok
         h = F.layer_norm(tok, (D,), sd[f"{p}.norm2.weight"], sd[f"{p}.norm2.bias"], eps)
-        h = F.gelu(F.linear(h, sd[f"{p}.mlp.fc1.weight"], sd[f"{p}.mlp.fc1.bias"]))
-        h = F.linear(h, sd[f"{p}.mlp.fc2.weight"], sd[f"{p}.mlp.fc2.bias"])
+        if f"{p}.mlp.weights_in.weight" in sd:      # dinov2-giant: HF Dinov2SwiGLUFFN — x1, x2 = weights_in(h).chunk(2); weights_out(silu(x1) * x2)
+            x1, x2 = F.linear(h, sd[f"{p}.mlp.weights_in.weight"], sd[f"{p}.mlp.weights_in.bias"]).chunk(2, dim=-1)
+            h = F.linear(F.silu(x1) * x2, sd[f"{p}.mlp.weights_out.weight"], sd[f"{p}.mlp.weights_out.bias"])
+        else:
+            h = F.gelu(F.linear(h, sd[f"{p}.mlp.fc1.weight"], sd[f"{p}.mlp.fc1.bias"]))
+            h = F.linear(h, sd[f"{p}.mlp.fc2.weight"], sd[f"{p}.mlp.fc2.bias"])
         tok = h * sd[f"{p}.layer_scale2.lambda1"] + tok
         i += 1
     tok = F.layer_norm(tok, (D,), sd["layernorm.weight"], sd["layernorm.bias"], eps)

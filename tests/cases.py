@@ -38,7 +38,8 @@ def si_net_sd(salt: str = "") -> Dict[str, torch.Tensor]:
 
 def dino_sd(size: str = "small") -> Dict[str, torch.Tensor]:
     c = synth.DINOV2_CONFIGS[size]
-    return sd_torch(synth.dinov2_shapes(c["hidden"], c["layers"]), prefix=f"dinov2-{size}.")
+    name = size.split("-")[0]              # "giant-l4" = the first 4 blocks of giant: same tensor names, same weights
+    return sd_torch(synth.dinov2_shapes(c["hidden"], c["layers"], swiglu=c.get("swiglu", False)), prefix=f"dinov2-{name}.")
 
 
 def siglip_sd(name: str = "tiny") -> Dict[str, torch.Tensor]:

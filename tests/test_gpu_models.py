@@ -244,6 +244,20 @@ def test_dino_large_golden(dev, prec):
         assert max_err(out, g[f"large_224_{kind}"]) < DINO_TOL[prec], (prec, kind, max_err(out, g[f"large_224_{kind}"]))
 
 
+@pytest.mark.parametrize("size,prec", [("giant-l4", "fp32"), ("giant-l4", "fp16"), ("giant-l4", "bf16"), ("giant", "fp32"), ("giant", "fp16")])
+def test_dino_giant_swiglu_golden(dev, size, prec):
+    """dinov2-giant (hidden 1536, 24 heads, gated SwiGLU FFN of width 4096; the fourth size the reference's DINOv2Encoder offers) against the
+    reference's own output: its first 4 blocks in every precision, the whole 40-block model in fp32 and fp16 (its low-precision mode)."""
+    from vlatouch.engine import DinoEngine
+    tag = size.replace("-", "_")
+    g = G(f"g3_dino_{tag}")
+    eng = DinoEngine(cases.dino_sd(size), heads=24, precision=prec, device=dev)
+    assert eng.swiglu
+    for kind in ("bright", "dark"):
+        out = eng.forward([cases.frames(2, 224, kind)], nhwc=False)[0]
+        assert max_err(out, g[f"{tag}_224_{kind}"]) < DINO_TOL[prec], (size, prec, kind, max_err(out, g[f"{tag}_224_{kind}"]))
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16"])
 def test_dino_base_golden_and_two_cameras(dev, dino_engines, prec):
     g = G("g3_dino_cls")

@@ -101,6 +101,15 @@ def test_g3_dino_large():
         close(od.encode(sd, cases.frames(2, 224, kind), 16), g[f"large_224_{kind}"], 5e-5, kind)
 
 
+def test_g3_dino_giant_swiglu():
+    """dinov2-giant's gated FFN (HF Dinov2SwiGLUFFN) at its real width (hidden 1536, 24 heads, F = 4096), on the first 4 of its 40 blocks (same tensor
+    names and weights; the whole model is checked on the GPU): fixture from the reference class (tools/make_golden_dino_large.py giant-l4)."""
+    g = G("g3_dino_giant_l4")
+    sd = cases.dino_sd("giant-l4")
+    for kind in ("bright", "dark"):
+        close(od.encode(sd, cases.frames(2, 224, kind), 24), g[f"giant_l4_224_{kind}"], 5e-5, kind)
+
+
 def test_g5_predict_end_to_end():
     g = G("g5_predict_e2e")
     inp = cases.predict_inputs(2, 16, 224)

@@ -25,7 +25,8 @@ struct half_t { uint16_t b; };   // raw IEEE binary16 bits, a distinct type so t
 // F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only).  F16: IEEE half storage + v_mfma_f32_16x16x32_f16
 // (same rate as bf16, 3 more mantissa bits; used where activations are range-bounded, i.e. the DINOv2 encoders).
 enum { VT_F32 = 0, VT_BF16 = 1, VT_F32X3 = 2, VT_F16 = 3 };
-enum { VT_ACT_NONE = 0, VT_ACT_GELU_ERF = 1, VT_ACT_GELU_TANH = 2, VT_ACT_SILU = 3, VT_ACT_MISH = 4 };
+enum { VT_ACT_NONE = 0, VT_ACT_GELU_ERF = 1, VT_ACT_GELU_TANH = 2, VT_ACT_SILU = 3, VT_ACT_MISH = 4,
+       VT_ACT_SWIGLU = 5 };    // not an element-wise epilogue: a ViT FFN form (vt_dino_desc.act): fc1 -> [x1 | x2], silu(x1) * x2, fc2 (HF Dinov2SwiGLUFFN)
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 typedef __attribute__((ext_vector_type(2))) float float2_t;

@@ -69,6 +69,7 @@ int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, 
                      const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
                      float hn_eps, int hn_mode, hipStream_t s);
 int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
+int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s);       // h[r][c] = silu(h[r][c]) * h[r][F + c], c < F, in place
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);
 int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
                     float noise_scale, float d, float score_eps, int backward, hipStream_t s);

@@ -418,6 +418,27 @@ __global__ void act_copy_kernel(const TI* __restrict__ in, long ldi, TO* __restr
   out[(long)r * ldo + c] = Elem<TO>::from_f(act_apply(Elem<TI>::to_f(in[(long)r * ldi + c]), act));
 }
 
+// SwiGLU gate, in place: h[r][c] = silu(h[r][c]) * h[r][F + c] for c < F (rows of 2 F values; HF Dinov2SwiGLUFFN: x1, x2 = hidden.chunk(2)); 8 / 4 elements per thread
+template <typename T>
+__global__ void swiglu_kernel(T* __restrict__ h, long ld, long rows, int F) {
+  constexpr int V = 16 / sizeof(T);
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_row = F / V;
+  if (i >= rows * per_row) return;
+  const long r = i / per_row;
+  const int c = (int)(i - r * per_row) * V;
+  T* p1 = h + r * ld + c;
+  uint4 a = *reinterpret_cast<const uint4*>(p1), b = *reinterpret_cast<const uint4*>(p1 + F);
+  T* av = reinterpret_cast<T*>(&a);
+  const T* bv = reinterpret_cast<const T*>(&b);
+#pragma unroll
+  for (int k = 0; k < V; ++k) {
+    const float x1 = Elem<T>::to_f(av[k]), x2 = Elem<T>::to_f(bv[k]);
+    av[k] = Elem<T>::from_f(x1 * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x1)) * x2);
+  }
+  *reinterpret_cast<uint4*>(p1) = a;
+}
+
 __global__ void sde_update_kernel(float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ s,
                                   const float* __restrict__ z, long n, float dt, float gi, float gdg, float eps, float noise_scale, float d,
                                   float score_eps, int backward) {
@@ -647,6 +668,13 @@ int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int d
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s) {
   DISPATCH_T(idt, TI, DISPATCH_T(odt, TO, hipLaunchKernelGGL((act_copy_kernel<TI, TO>), g1((long)rows * cols), dim3(256), 0, s, (const TI*)in, ldi,
                                                               (TO*)out, ldo, rows, cols, act)))
+  return vt_check_launch();
+}
+
+int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s) {
+  const int V = (dt == VT_F32) ? 4 : 8;
+  if (F % V || ld % V || rows <= 0) return VT_ERR_ARG;
+  DISPATCH_T(dt, T, hipLaunchKernelGGL((swiglu_kernel<T>), g1(rows * (F / V)), dim3(256), 0, s, (T*)h, ld, rows, F))
   return vt_check_launch();
 }
 

@@ -4,6 +4,7 @@
 //   0 patch_w [D][kpad] cdt   1 patch_b [D]   2 cls_pos0 [D] (= cls_token + position_embeddings[0])
 //   per layer (14 entries): ln1_w ln1_b  qkv_w [3D][D] cdt  qkv_b [3D]  proj_w [D][D] cdt  proj_b  ls1
 //                           ln2_w ln2_b  fc1_w [4D][D] cdt  fc1_b  fc2_w [D][4D] cdt  fc2_b  ls2
+//                           (act = VT_ACT_SWIGLU, dinov2-giant: fc1_w = weights_in [2F][D], fc2_w = weights_out [D][F], F = mlp_dim)
 //   then  lnf_w  lnf_b
 // The residual stream (tokens) is kept in fp32; normalised activations / QKV / MLP hidden are `adt`.
 //
@@ -82,7 +83,7 @@ DWs dcarve(const vt_dino_s* h, int Bt, int res) {
   w.xn = take((size_t)Bt * N * D * a);
   w.qkv = take((size_t)Bt * N * 3 * Da * a);
   w.att = take((size_t)Bt * N * Da * a);
-  w.h1 = take((size_t)Bt * N * Dm * a);
+  w.h1 = take((size_t)Bt * N * Dm * a * (d.act == VT_ACT_SWIGLU ? 2 : 1));      // SwiGLU: fc1 produces [x1 | x2]
   w.total = o;
   return w;
 }
@@ -124,6 +125,18 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
   // The reference consumes only pooler_output = the CLS row of the last layer (visual_encoder.py:88-93): in the LAST block every token still feeds
   // K and V, but only the CLS row needs a query, the output projection, the MLP and the residual updates (SURVEY 2.1 "last layer prunes to the CLS
   // query").  VLATOUCH_DINO_CLS_LAST=0 runs the last block on all tokens (A/B; same CLS row up to the summation order of the small-M GEMM tiles).
+  // the FFN of a block on `rows` rows of xn (row stride D) -> tok rows (row stride tstride_out): fc1 (+ activation, or the SwiGLU gate) -> fc2 + LayerScale + residual
+  const bool swiglu = act == VT_ACT_SWIGLU;
+  auto ffn = [&](const DinoLayer& L, int rows, long tok_stride) -> int {
+    const int N1 = swiglu ? 2 * Dm : Dm;
+    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, N1, rows, N1, D, swiglu ? VT_ACT_NONE : act);
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
+    if (swiglu) CK(vt_wrap(vt_k_swiglu(ws + w.h1, d.adt, N1, rows, Dm, s), "dino swiglu gate"));
+    { VtGemmParams p = lin(ws + w.h1, d.adt, N1, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tok_stride, rows, D, Dm, VT_ACT_NONE);
+      p.colscale = L.ls2; p.residual = tok; p.ldr = tok_stride;
+      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2")); }
+    return VT_OK;
+  };
   static const bool cls_last_on = [] { const char* e = getenv("VLATOUCH_DINO_CLS_LAST"); return !e || atoi(e) != 0; }();
   for (int l = 0; l < d.layers; ++l) {
     const DinoLayer& L = h->L[l];
@@ -148,11 +161,7 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
         p.colscale = L.ls1; p.residual = tok; p.ldr = tstride;
         CK(vt_wrap(vt_gemm_launch(p, s), "dino proj (CLS rows)")); }
       CK(vt_k_rownorm(tok, VT_F32, tstride, ws + w.xn, d.adt, D, L.ln2_w, L.ln2_b, Bt, D, d.eps, VT_NORM_LAYER, s));
-      { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, Dm, Bt, Dm, D, act);
-        CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1 (CLS rows)")); }
-      { VtGemmParams p = lin(ws + w.h1, d.adt, Dm, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tstride, Bt, D, Dm, VT_ACT_NONE);
-        p.colscale = L.ls2; p.residual = tok; p.ldr = tstride;
-        CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2 (CLS rows)")); }
+      CK(ffn(L, Bt, tstride));
       continue;
     }
     { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.qkv_w, d.cdt, D, L.qkv_b, ws + w.qkv, d.adt, 3 * Da, M, 3 * Da, D, VT_ACT_NONE);
@@ -168,11 +177,7 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
       p.colscale = L.ls1; p.residual = tok; p.ldr = D;
       CK(vt_wrap(vt_gemm_launch(p, s), "dino proj")); }
     CK(vt_k_rownorm(tok, VT_F32, D, ws + w.xn, d.adt, D, L.ln2_w, L.ln2_b, M, D, d.eps, VT_NORM_LAYER, s));
-    { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, Dm, M, Dm, D, act);
-      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
-    { VtGemmParams p = lin(ws + w.h1, d.adt, Dm, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, D, M, D, Dm, VT_ACT_NONE);
-      p.colscale = L.ls2; p.residual = tok; p.ldr = D;
-      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2")); }
+    CK(ffn(L, M, D));
   }
   // 3. final LayerNorm: on the CLS rows only -> pooler_output (DINOv2), or on every token -> last_hidden_state (SigLIP)
   if (d.out_all) CK(vt_k_rownorm(tok, VT_F32, D, out, VT_F32, D, h->lnf_w, h->lnf_b, M, D, d.eps, VT_NORM_LAYER, s));

@@ -77,12 +77,10 @@ class DINOv2Encoder:
         self.patch_size = 14
         self.hidden_size = cfg["hidden"]
         self.precision = precision or default_precision()
-        if size == "giant":
-            raise NotImplementedError("dinov2-giant uses a SwiGLU FFN, which this engine does not implement")
         sd = state_dict if state_dict is not None else _find_weights(model_name)
         if sd is None:
             if os.environ.get("VLATOUCH_SYNTH_WEIGHTS") == "1":
-                shapes = synth.dinov2_shapes(cfg["hidden"], cfg["layers"])
+                shapes = synth.dinov2_shapes(cfg["hidden"], cfg["layers"], swiglu=(size == "giant"))
                 sd = {k: torch.from_numpy(v) for k, v in synth.fill_state_dict(shapes, prefix=f"dinov2-{size}.").items()}
             else:
                 raise FileNotFoundError(

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvlatouch_hip.so")
 
 F32, BF16, F32X3, F16 = 0, 1, 2, 3   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only); F16: IEEE half
-ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH, ACT_SWIGLU = 0, 1, 2, 3, 4, 5
 NORM_LAYER, NORM_RMS_MEANSQ, NORM_RMS_VAR = 0, 1, 2
 IMGNORM_AUTO, IMGNORM_ON, IMGNORM_OFF = 0, 1, 2
 

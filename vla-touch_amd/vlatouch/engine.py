@@ -237,6 +237,9 @@ class DinoEngine:
         while f"encoder.layer.{layers}.norm1.weight" in sd:
             layers += 1
         self.layers = layers
+        # dinov2-giant: gated FFN (HF Dinov2SwiGLUFFN: weights_in [2F, D] -> silu(x1) * x2 -> weights_out [D, F]); the others: fc1 / GELU / fc2
+        self.swiglu = "encoder.layer.0.mlp.weights_in.weight" in sd
+        fc1n, fc2n = ("mlp.weights_in", "mlp.weights_out") if self.swiglu else ("mlp.fc1", "mlp.fc2")
         dev = self.device
         pwp = torch.zeros(D, self.kpad)
         pwp[:, : 3 * patch * patch] = pw.reshape(D, -1)
@@ -252,8 +255,8 @@ class DinoEngine:
                   g(f"{p}.attention.output.dense.weight").to(wdt).to(dev), g(f"{p}.attention.output.dense.bias").to(dev),
                   g(f"{p}.layer_scale1.lambda1").to(dev),
                   g(f"{p}.norm2.weight").to(dev), g(f"{p}.norm2.bias").to(dev),
-                  g(f"{p}.mlp.fc1.weight").to(wdt).to(dev), g(f"{p}.mlp.fc1.bias").to(dev),
-                  g(f"{p}.mlp.fc2.weight").to(wdt).to(dev), g(f"{p}.mlp.fc2.bias").to(dev),
+                  g(f"{p}.{fc1n}.weight").to(wdt).to(dev), g(f"{p}.{fc1n}.bias").to(dev),
+                  g(f"{p}.{fc2n}.weight").to(wdt).to(dev), g(f"{p}.{fc2n}.bias").to(dev),
                   g(f"{p}.layer_scale2.lambda1").to(dev)]
         W += [g("layernorm.weight").to(dev), g("layernorm.bias").to(dev)]
         W = [w.contiguous() for w in W]
@@ -261,6 +264,8 @@ class DinoEngine:
         desc = L.DinoDesc()
         desc.hidden, desc.layers, desc.heads, desc.patch, desc.kpad = D, layers, heads, patch, self.kpad
         desc.cdt, desc.adt, desc.eps = cdt, adt, eps
+        if self.swiglu:
+            desc.act, desc.mlp_dim = L.ACT_SWIGLU, sd[f"encoder.layer.0.{fc2n}.weight"].shape[1]
         lib = L.lib()
         assert lib.vt_dino_num_weights(C.byref(desc)) == len(W)
         self._h = C.c_void_p()

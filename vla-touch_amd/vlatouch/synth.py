@@ -18,7 +18,7 @@ from typing import Dict, Iterable, Mapping, Sequence, Tuple
 
 import numpy as np
 
-__all__ = ["tensor", "fill_state_dict", "inputs_rng", "unet_shapes", "si_net_shapes",
+__all__ = ["swiglu_hidden", "tensor", "fill_state_dict", "inputs_rng", "unet_shapes", "si_net_shapes",
            "dinov2_shapes", "DINOV2_CONFIGS", "state_encoder_shapes", "lstm_controller_shapes",
            "rdt_runner_shapes"]
 
@@ -151,10 +151,17 @@ DINOV2_CONFIGS = {
     "small": dict(hidden=384, layers=12, heads=6),
     "base": dict(hidden=768, layers=12, heads=12),
     "large": dict(hidden=1024, layers=24, heads=16),
+    "giant": dict(hidden=1536, layers=40, heads=24, swiglu=True),          # SwiGLU FFN (HF Dinov2SwiGLUFFN): weights_in [2 F, D], weights_out [D, F]
+    "giant-l4": dict(hidden=1536, layers=4, heads=24, swiglu=True),        # the first 4 blocks of giant (same tensor names): a light fixture of the SwiGLU arithmetic
 }
 
 
-def dinov2_shapes(hidden: int, layers: int, heads: int = 0, image_size: int = 518, patch: int = 14) -> Dict[str, Tuple[int, ...]]:
+def swiglu_hidden(hidden: int, mlp_ratio: int = 4) -> int:
+    """Width F of HF Dinov2SwiGLUFFN: (int(hidden * mlp_ratio * 2 / 3) + 7) // 8 * 8 (1536 -> 4096)."""
+    return (int(hidden * mlp_ratio * 2 / 3) + 7) // 8 * 8
+
+
+def dinov2_shapes(hidden: int, layers: int, heads: int = 0, image_size: int = 518, patch: int = 14, swiglu: bool = False) -> Dict[str, Tuple[int, ...]]:
     """HF Dinov2Model key map."""
     n_pos = (image_size // patch) ** 2 + 1
     D = hidden
@@ -177,10 +184,17 @@ def dinov2_shapes(hidden: int, layers: int, heads: int = 0, image_size: int = 51
         d[f"{p}.layer_scale1.lambda1"] = (D,)
         d[f"{p}.norm2.weight"] = (D,)
         d[f"{p}.norm2.bias"] = (D,)
-        d[f"{p}.mlp.fc1.weight"] = (4 * D, D)
-        d[f"{p}.mlp.fc1.bias"] = (4 * D,)
-        d[f"{p}.mlp.fc2.weight"] = (D, 4 * D)
-        d[f"{p}.mlp.fc2.bias"] = (D,)
+        if swiglu:
+            Fh = swiglu_hidden(D)
+            d[f"{p}.mlp.weights_in.weight"] = (2 * Fh, D)
+            d[f"{p}.mlp.weights_in.bias"] = (2 * Fh,)
+            d[f"{p}.mlp.weights_out.weight"] = (D, Fh)
+            d[f"{p}.mlp.weights_out.bias"] = (D,)
+        else:
+            d[f"{p}.mlp.fc1.weight"] = (4 * D, D)
+            d[f"{p}.mlp.fc1.bias"] = (4 * D,)
+            d[f"{p}.mlp.fc2.weight"] = (D, 4 * D)
+            d[f"{p}.mlp.fc2.bias"] = (D,)
         d[f"{p}.layer_scale2.lambda1"] = (D,)
     d["layernorm.weight"] = (D,)
     d["layernorm.bias"] = (D,)
