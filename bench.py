@@ -10,8 +10,8 @@ denormalised refined chunks [B, T, 10].  Inputs are resident in HBM before the t
 noise is drawn on device inside the step (as the reference does).  Episodes are independent: ranks take disjoint
 batches (weak scaling), frozen weights are broadcast once from rank 0 over RCCL, no collective in the step loop.
 
-Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` (dominant kernel = gemm_pp256_kernel, the
-256-square ping-pong MFMA GEMM tile, timed live with HIP events on its launch stream; `roofline_other` carries the same
+Prints ONE JSON line (rank 0) with the BASELINE.json metric plus `roofline` (dominant kernel class = the 256-square ping-pong MFMA GEMM tile,
+gemm_pt_kernel / gemm_pp256d_kernel, timed live with HIP events on its launch stream; `roofline_other` carries the same
 figures for the 128-column GEMM kernel) and `cpu_baseline` (the oracle on the host cores).
 """
 from __future__ import annotations
@@ -437,8 +437,9 @@ def main():
                      "d2d_copy_GBs": round(5 * 2 * src.numel() * 4 / (e[1].elapsed_time(e[2]) * 1e-3) / 1e9, 1)}
             del a8, w8, o8, src, dst
 
-    r_pp = roof(2, "gemm_pp256d_kernel (256x256x64 ping-pong tile, deep-prefetch schedule, 16-bit MFMA: fused condition K|V projections, image adaptor, "
-                   "RDT qkv projections, DINOv2 Linears)", "gemm_pp256")
+    r_pp = roof(2, "gemm_pt_kernel + gemm_pp256d_kernel (256x256x64 ping-pong tile, 16-bit MFMA; gemm_pt = persistent, operand stream continuous across tiles, "
+                   "epilogue on registers inside the k-loop: fused condition K|V projections of RDT, image / language adaptors, DINOv2 qkv / fc1 / out-projection / fc2; "
+                   "gemm_pp256d = the same tile, one launch block per tile, for the epilogue kinds the persistent kernel does not have)", "gemm_pp256")
     r_gl = roof(3, "gemm_pw_kernel (160x128x64 tile, frozen fragment-packed weights streamed global -> VGPR, activations through an LDS-DMA ring; with the few "
                    "gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows, incl. the fused qkv projection)", "gemm_pw")
     r_at = None
