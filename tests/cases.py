@@ -60,9 +60,10 @@ def force_decoder_sd() -> Dict[str, torch.Tensor]:
     return sd_torch(synth.force_decoder_shapes(), prefix="force_decoder.")
 
 
-def lstm_mods(latent: int = 384) -> Dict[str, Dict[str, torch.Tensor]]:
-    shp = synth.lstm_controller_shapes(latent)
-    return {m: sd_torch(s, prefix=f"lstm_ctrl.{m}.") for m, s in shp.items()}
+def lstm_mods(latent: int = 384, hidden: int = 256, layers: int = 2) -> Dict[str, Dict[str, torch.Tensor]]:
+    shp = synth.lstm_controller_shapes(latent, hidden=hidden, layers=layers)
+    tag = "" if (hidden, layers) == (256, 2) else f"h{hidden}l{layers}."           # other widths / depths: their own deterministic weights
+    return {m: sd_torch(s, prefix=f"lstm_ctrl.{tag}{m}.") for m, s in shp.items()}
 
 
 RDT_TINY = dict(hidden=256, depth=4, heads=4, horizon=8, action_dim=128, lang_token_dim=96, img_token_dim=80,
@@ -173,9 +174,9 @@ def synth_episode(seed: int, N: int, res: int = 28) -> Dict[str, np.ndarray]:
     }
 
 
-def lstm_inputs(B: int, Tlen: int, seed: int = 5):
+def lstm_inputs(B: int, Tlen: int, seed: int = 5, hidden: int = 256):
     g = synth.inputs_rng(seed)
-    return dict(obs_cond=T(g.standard_normal((B, 256), dtype=np.float32)),
+    return dict(obs_cond=T(g.standard_normal((B, hidden), dtype=np.float32)),
                 vla=T(g.uniform(0, 1, (B, Tlen, 10)).astype(np.float32)),
                 forces=T(g.standard_normal((B, Tlen, 3), dtype=np.float32)))
 

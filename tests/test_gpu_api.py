@@ -174,6 +174,36 @@ def test_lstm_controller_golden(prec):
         assert torch.equal(c2.predict_sequence(li["obs_cond"], li["vla"], li["forces"]), seq)
 
 
+@pytest.mark.parametrize("hidden,layers", [(128, 2), (384, 3)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_lstm_controller_other_widths_golden(prec, hidden, layers):
+    """`lstm_train.py --hidden_dim` 128 / 384 (2 / 3 LSTM layers): the persistent sequence kernel templated on the hidden size, against the reference
+    class's own run (g6_lstm_h*: forward, predict_sequence with carried state, observation encoding); ragged batch (3 rows of a 16-row block)."""
+    from residual_controller.lstm_step_controller import TactileLSTMController
+    from residual_controller.controller_dataset import normalize_actions
+    g = G(f"g6_lstm_h{hidden}l{layers}")
+    c = TactileLSTMController(hidden_dim=hidden, num_layers=layers, device="cuda:0", precision=prec, image_state_dict=cases.dino_sd("small"))
+    for name, sd in cases.lstm_mods(384, hidden=hidden, layers=layers).items():
+        getattr(c, name).load_state_dict(sd)
+    c.to("cuda:0")
+    c.stats = cases.stats("nontrivial")
+    li = cases.lstm_inputs(3, 16, hidden=hidden)
+    seq = c.predict_sequence(li["obs_cond"], li["vla"], li["forces"])
+    assert err(seq, g["predict_sequence"]) < 1e-4, err(seq, g["predict_sequence"])
+    assert err(c.hidden_state, g["h"]) < 1e-4 and err(c.cell_state, g["c"]) < 1e-4
+    vn = normalize_actions(li["vla"], c.stats, "vla")
+    assert err(c.forward({"vla_act": vn, "obs_cond": li["obs_cond"], "forces": li["forces"]}), g["forward"]) < 1e-4
+    pi = cases.predict_inputs(2, 16, 224)
+    assert err(c.encode_observation(pi["state"], pi["cam1"], pi["cam2"]), g["obs_cond"]) < (2e-4 if prec == "fp32" else 3e-2)
+
+
+def test_lstm_controller_rejects_widths_the_kernel_cannot_deal():
+    from residual_controller.lstm_step_controller import TactileLSTMController
+    for bad in (64, 200, 512):
+        with pytest.raises(ValueError):
+            TactileLSTMController(hidden_dim=bad, device="cuda:0", image_state_dict=cases.dino_sd("small"))
+
+
 def test_no_cpu_fallback():
     from vlatouch import _lib
     with pytest.raises(_lib.VtError):

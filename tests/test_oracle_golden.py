@@ -133,6 +133,21 @@ def test_g6_lstm():
           g["obs_cond"], 3e-5, "obs")
 
 
+@pytest.mark.parametrize("hidden,layers", [(128, 2), (384, 3)])
+def test_g6_lstm_other_widths(hidden, layers):
+    """The LSTM head at `--hidden_dim` 128 / 384 (lstm_train.py; every width of the head scales with it) against the reference class's own run
+    (tools/make_golden_lstm_widths.py)."""
+    g = G(f"g6_lstm_h{hidden}l{layers}")
+    mods = cases.lstm_mods(384, hidden=hidden, layers=layers)
+    st = cases.stats("nontrivial")
+    li = cases.lstm_inputs(3, 16, hidden=hidden)
+    vn = on.normalize_actions(li["vla"], st, "vla")
+    close(oc.lstm_forward(mods, li["obs_cond"], vn, li["forces"], layers, hidden), g["forward"], 2e-5, "forward")
+    close(oc.lstm_predict_sequence(mods, st, li["obs_cond"], li["vla"], li["forces"], layers, hidden), g["predict_sequence"], 2e-5, "seq")
+    pi = cases.predict_inputs(2, 16, 224)
+    close(oc.lstm_encode_observation(cases.dino_sd("small"), 6, mods["obs_encoder"], pi["state"], pi["cam1"], pi["cam2"]), g["obs_cond"], 3e-5, "obs")
+
+
 def test_g7_normalize():
     g = G("g7_norm")
     st = cases.stats("nontrivial")

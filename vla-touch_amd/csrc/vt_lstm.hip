@@ -28,12 +28,17 @@
 
 namespace {
 
-constexpr int H = 256;                 // LSTM hidden size (the reference's hidden_dim; the wave <-> hidden-unit deal assumes it)
+// LSTM hidden size H (the reference's --hidden_dim, lstm_step_controller.py:16; every width of the head scales with it: force MLP H/2, LSTM H,
+// head 2H -> H) is a template parameter: 128, 256 (the reference's default) or 384 — multiples of 128, so that each of the 8 waves owns H/8 =
+// UT x 16 hidden units with all four gates in the same lanes.  (512 would need 170 KiB of LDS for two layers.)
 constexpr int ROWS = 16;               // batch rows per block
-constexpr int LDH = H + 4;             // fp32 LDS row pitches: (pitch mod 64) in {4, 36} keeps the 16-row ds_read_b128 pattern conflict-free
-constexpr int KX = 160, LDX = KX + 4;  // layer-0 input [force features 128 | vla_n S | 0 ...] padded to 5 k-steps
 constexpr int KF = 32, LDF = KF + 4;   // raw force, padded to one k-step
-constexpr int LDF1 = 128 + 4;
+template <int H> struct LstmDims {
+  static constexpr int UT = H / 128;                                   // 16-unit tiles per gate per wave
+  static constexpr int LDH = H + 4;                                    // fp32 LDS row pitches: (pitch mod 64) == 4 keeps the 16-row ds_read_b128 pattern conflict-free
+  static constexpr int KX = (H / 2 + 16 + 31) / 32 * 32, LDX = KX + 4; // layer-0 input [force features H/2 | vla_n S <= 16 | 0 ...] padded to whole k-steps (H = 256: 160)
+  static constexpr int HF = H / 2, LDF1 = HF + 4;                      // force-MLP width
+};
 
 struct LstmSeqParams {
   const void *fe1, *fe2, *wl[4], *h1, *h2;
@@ -113,8 +118,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rc
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + fast_exp(2.0f * x)); }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <typename TW, int NL>
+template <typename TW, int NL, int H>
 __global__ __launch_bounds__(512) void lstm_seq_kernel(const LstmSeqParams p) {
+  using Dm = LstmDims<H>;
+  constexpr int UT = Dm::UT, LDH = Dm::LDH, KX = Dm::KX, LDX = Dm::LDX, HF = Dm::HF, LDF1 = Dm::LDF1, UW = H / 8;   // UW = hidden units per wave
   __shared__ __attribute__((aligned(16))) float hS[NL][ROWS][LDH];    // h of every layer
   __shared__ __attribute__((aligned(16))) float obsS[ROWS][LDH];
   __shared__ __attribute__((aligned(16))) float hdS[ROWS][LDH];
@@ -130,14 +137,14 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const LstmSeqParams p) {
   const int brow = min(b0 + l15, p.B - 1);            // the batch row this lane's MFMA column stands for (clamped: computed, never stored)
   const bool row_ok = b0 + l15 < p.B;
 
-  // ---- entry: h -> LDS, c -> registers (lane owns units j = 32*wave + 16*t + 4*g + r of row l15), obs_cond -> LDS
-  float cR[NL][2][4];
+  // ---- entry: h -> LDS, c -> registers (lane owns units j = UW*wave + 16*t + 4*g + r of row l15), obs_cond -> LDS
+  float cR[NL][UT][4];
 #pragma unroll
   for (int l = 0; l < NL; ++l)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < UT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) cR[l][t][r] = p.c[((long)l * p.B + brow) * H + wave * 32 + t * 16 + g * 4 + r];
+      for (int r = 0; r < 4; ++r) cR[l][t][r] = p.c[((long)l * p.B + brow) * H + wave * UW + t * 16 + g * 4 + r];
   for (int e = tid; e < L * ROWS * (H / 4); e += 512) {
     const int l = e / (ROWS * (H / 4)), rem = e - l * (ROWS * (H / 4)), m = rem / (H / 4), c4 = rem - m * (H / 4);
     *reinterpret_cast<float4*>(&hS[l][m][c4 * 4]) = *reinterpret_cast<const float4*>(p.h + ((long)l * p.B + min(b0 + m, p.B - 1)) * H + c4 * 4);
@@ -152,90 +159,113 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const LstmSeqParams p) {
   __syncthreads();
 
   for (int tk = 0; tk < p.T; ++tk) {
-    // ---- inputs of the tick: raw force -> finS, vla_n -> xinS[:, 128 : 128 + S]
+    // ---- inputs of the tick: raw force -> finS, vla_n -> xinS[:, H/2 : H/2 + S]
     if (tid < ROWS * 32) {
       const int m = tid >> 5, k = tid & 31;
       const long bt = (long)min(b0 + m, p.B - 1) * p.T + tk;
       if (k < F) finS[m][k] = p.force[bt * F + k];
-      if (k < S) xinS[m][128 + k] = p.vla[bt * S + k];
+      if (k < S) xinS[m][HF + k] = p.vla[bt * S + k];
     }
     __syncthreads();
-    // ---- force MLP: Linear(F -> 128) GELU(erf) Linear(128 -> 128); wave w computes columns [16w, 16w + 16)
-    {
+    // ---- force MLP: Linear(F -> H/2) GELU(erf) Linear(H/2 -> H/2); the H/32 column tiles of 16 are dealt round-robin over the 8 waves
+    for (int tile = wave; tile < HF / 16; tile += 8) {
       float4_t a[1] = {(float4_t){0.f, 0.f, 0.f, 0.f}};
-      mm<TW, 1>(a, p.fe1, wave, 1, 0, &finS[0][0], LDF, 1, lane);
+      mm<TW, 1>(a, p.fe1, tile, 1, 0, &finS[0][0], LDF, 1, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int n = wave * 16 + g * 4 + r; f1S[l15][n] = gelu_erf(a[0][r] + p.fe_b1[n]); }
+      for (int r = 0; r < 4; ++r) { const int n = tile * 16 + g * 4 + r; f1S[l15][n] = gelu_erf(a[0][r] + p.fe_b1[n]); }
     }
     __syncthreads();
-    {
+    for (int tile = wave; tile < HF / 16; tile += 8) {
       float4_t a[1] = {(float4_t){0.f, 0.f, 0.f, 0.f}};
-      mm<TW, 1>(a, p.fe2, wave, 4, 0, &f1S[0][0], LDF1, 4, lane);
+      mm<TW, 1>(a, p.fe2, tile, HF / 32, 0, &f1S[0][0], LDF1, HF / 32, lane);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { const int n = wave * 16 + g * 4 + r; xinS[l15][n] = a[0][r] + p.fe_b2[n]; }
+      for (int r = 0; r < 4; ++r) { const int n = tile * 16 + g * 4 + r; xinS[l15][n] = a[0][r] + p.fe_b2[n]; }
     }
     __syncthreads();
-    // ---- LSTM layers: gates = [x | h_l] W_cat^T + (b_ih + b_hh); tiles of wave w: 8*w + 2*q + t <-> rows q*256 + 32w + 16t ..
+    // ---- LSTM layers: gates = [x | h_l] W_cat^T + (b_ih + b_hh); tiles of wave w: 4 UT w + UT q + t <-> rows q*H + UW w + 16t ..
 #pragma unroll
     for (int l = 0; l < NL; ++l) {
       const int xks = l == 0 ? KX / 32 : H / 32;                 // k-steps of the layer input
       const int wks = xks + H / 32;
-      float4_t acc[8];
+      float4_t acc[4 * UT];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-      mm<TW, 8>(acc, p.wl[l], wave * 8, wks, 0, l == 0 ? &xinS[0][0] : &hS[l - 1][0][0], l == 0 ? LDX : LDH, xks, lane);
-      mm<TW, 8>(acc, p.wl[l], wave * 8, wks, xks, &hS[l][0][0], LDH, H / 32, lane);
-      float hn[2][4];
+      for (int i = 0; i < 4 * UT; ++i) acc[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      mm<TW, 4 * UT>(acc, p.wl[l], wave * 4 * UT, wks, 0, l == 0 ? &xinS[0][0] : &hS[l - 1][0][0], l == 0 ? LDX : LDH, xks, lane);
+      mm<TW, 4 * UT>(acc, p.wl[l], wave * 4 * UT, wks, xks, &hS[l][0][0], LDH, H / 32, lane);
+      float hn[UT][4];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < UT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int j = wave * 32 + t * 16 + g * 4 + r;
+          const int j = wave * UW + t * 16 + g * 4 + r;
           const float* bl = p.bl[l];
-          const float gi = acc[0 + t][r] + bl[j], gf = acc[2 + t][r] + bl[H + j], gg = acc[4 + t][r] + bl[2 * H + j], go = acc[6 + t][r] + bl[3 * H + j];
+          const float gi = acc[0 * UT + t][r] + bl[j], gf = acc[1 * UT + t][r] + bl[H + j], gg = acc[2 * UT + t][r] + bl[2 * H + j], go = acc[3 * UT + t][r] + bl[3 * H + j];
           const float cn = sigmoidf_(gf) * cR[l][t][r] + sigmoidf_(gi) * tanhf_(gg);
           cR[l][t][r] = cn;
           hn[t][r] = sigmoidf_(go) * tanhf_(cn);
         }
       __syncthreads();                                           // every wave is done reading the old h_l
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        *reinterpret_cast<float4*>(&hS[l][l15][wave * 32 + t * 16 + g * 4]) = make_float4(hn[t][0], hn[t][1], hn[t][2], hn[t][3]);
+      for (int t = 0; t < UT; ++t)
+        *reinterpret_cast<float4*>(&hS[l][l15][wave * UW + t * 16 + g * 4]) = make_float4(hn[t][0], hn[t][1], hn[t][2], hn[t][3]);
       __syncthreads();
     }
-    // ---- head: Linear(2H -> H) on [h_top | obs_cond]; wave w computes columns [32w, 32w + 32)
+    // ---- head: Linear(2H -> H) on [h_top | obs_cond]; wave w computes columns [UW w, UW w + UW)
     {
-      float4_t a[2] = {(float4_t){0.f, 0.f, 0.f, 0.f}, (float4_t){0.f, 0.f, 0.f, 0.f}};
-      mm<TW, 2>(a, p.h1, wave * 2, 16, 0, &hS[L - 1][0][0], LDH, 8, lane);
-      mm<TW, 2>(a, p.h1, wave * 2, 16, 8, &obsS[0][0], LDH, 8, lane);
+      float4_t a[UT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < UT; ++t) a[t] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      mm<TW, UT>(a, p.h1, wave * UT, 2 * H / 32, 0, &hS[L - 1][0][0], LDH, H / 32, lane);
+      mm<TW, UT>(a, p.h1, wave * UT, 2 * H / 32, H / 32, &obsS[0][0], LDH, H / 32, lane);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int n = wave * 32 + t * 16 + g * 4 + r; hdS[l15][n] = a[t][r] + p.h1_b[n]; }
+      for (int t = 0; t < UT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int n = wave * UW + t * 16 + g * 4 + r; hdS[l15][n] = a[t][r] + p.h1_b[n]; }
     }
     __syncthreads();
-    // LayerNorm(eps 1e-5) + GELU(erf), in place: wave w normalises rows 2w and 2w + 1 (a lane holds 4 columns)
+    // LayerNorm(eps 1e-5) + GELU(erf), in place: wave w normalises rows 2w and 2w + 1; a lane holds the float4 chunks lane, lane + 64 (H = 128: lanes
+    // 0..31 one chunk; 256: one chunk per lane; 384: lanes 0..31 two)
+    constexpr int NCH = (H / 4 + 63) / 64;
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
       float* row = &hdS[wave * 2 + rr][0];
-      float4 v = *reinterpret_cast<float4*>(row + lane * 4);
-      const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / H);
-      const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
-      const float var = wave_sum((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3)) * (1.0f / H);
-      const float rstd = rsqrtf(var + 1e-5f);
-      const float4 w4 = *reinterpret_cast<const float4*>(p.ln_w + lane * 4), b4 = *reinterpret_cast<const float4*>(p.ln_b + lane * 4);
-      v = make_float4(gelu_erf(d0 * rstd * w4.x + b4.x), gelu_erf(d1 * rstd * w4.y + b4.y), gelu_erf(d2 * rstd * w4.z + b4.z), gelu_erf(d3 * rstd * w4.w + b4.w));
-      *reinterpret_cast<float4*>(row + lane * 4) = v;
+      float4 v[NCH];
+      float sm = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c4 = lane + 64 * k;
+        v[k] = c4 < H / 4 ? *reinterpret_cast<float4*>(row + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sm += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+      }
+      const float mean = wave_sum(sm) * (1.0f / H);
+      float q = 0.f;
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        if (lane + 64 * k < H / 4) {
+          v[k] = make_float4(v[k].x - mean, v[k].y - mean, v[k].z - mean, v[k].w - mean);
+          q += (v[k].x * v[k].x + v[k].y * v[k].y) + (v[k].z * v[k].z + v[k].w * v[k].w);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+#pragma unroll
+      for (int k = 0; k < NCH; ++k) {
+        const int c4 = lane + 64 * k;
+        if (c4 < H / 4) {
+          const float4 w4 = *reinterpret_cast<const float4*>(p.ln_w + c4 * 4), b4 = *reinterpret_cast<const float4*>(p.ln_b + c4 * 4);
+          *reinterpret_cast<float4*>(row + c4 * 4) = make_float4(gelu_erf(v[k].x * rstd * w4.x + b4.x), gelu_erf(v[k].y * rstd * w4.y + b4.y),
+                                                                 gelu_erf(v[k].z * rstd * w4.z + b4.z), gelu_erf(v[k].w * rstd * w4.w + b4.w));
+        }
+      }
     }
     __syncthreads();
     // Linear(H -> S) + vla_n: one tile, wave 0
     if (wave == 0) {
       float4_t a[1] = {(float4_t){0.f, 0.f, 0.f, 0.f}};
-      mm<TW, 1>(a, p.h2, 0, 8, 0, &hdS[0][0], LDH, 8, lane);
+      mm<TW, 1>(a, p.h2, 0, H / 32, 0, &hdS[0][0], LDH, H / 32, lane);
       if (row_ok) {
         const long bt = (long)(b0 + l15) * p.T + tk;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int n = g * 4 + r; if (n < S) p.out[bt * S + n] = a[0][r] + p.h2_b[n] + xinS[l15][128 + n]; }
+        for (int r = 0; r < 4; ++r) { const int n = g * 4 + r; if (n < S) p.out[bt * S + n] = a[0][r] + p.h2_b[n] + xinS[l15][HF + n]; }
       }
     }
     __syncthreads();                                             // finS / xinS / hdS are rewritten by the next tick
@@ -245,10 +275,10 @@ __global__ __launch_bounds__(512) void lstm_seq_kernel(const LstmSeqParams p) {
 #pragma unroll
     for (int l = 0; l < NL; ++l)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-          const long o = ((long)l * p.B + b0 + l15) * H + wave * 32 + t * 16 + g * 4;
+      for (int t = 0; t < UT; ++t) {
+          const long o = ((long)l * p.B + b0 + l15) * H + wave * UW + t * 16 + g * 4;
           *reinterpret_cast<float4*>(p.c + o) = make_float4(cR[l][t][0], cR[l][t][1], cR[l][t][2], cR[l][t][3]);
-          *reinterpret_cast<float4*>(p.h + o) = *reinterpret_cast<const float4*>(&hS[l][l15][wave * 32 + t * 16 + g * 4]);
+          *reinterpret_cast<float4*>(p.h + o) = *reinterpret_cast<const float4*>(&hS[l][l15][wave * UW + t * 16 + g * 4]);
         }
   }
 }
@@ -269,9 +299,12 @@ int vt_lstm_num_weights(const vt_lstm_desc* d) { return 4 + 2 * d->layers + 6; }
 int vt_lstm_create(const vt_lstm_desc* desc, const void* const* w, int n, vt_lstm_t* out) {
   if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_lstm_create: null argument");
   const vt_lstm_desc& d = *desc;
-  if (d.hidden != H) return vt_fail(VT_ERR_UNSUPPORTED, "vt_lstm_create: hidden must be %d (got %d)", H, d.hidden);
-  if (d.layers < 1 || d.layers > 4 || d.state_dim < 1 || d.state_dim > 16 || d.force_dim < 1 || d.force_dim > KF || H / 2 + d.state_dim > KX)
+  if (d.hidden != 128 && d.hidden != 256 && d.hidden != 384)
+    return vt_fail(VT_ERR_UNSUPPORTED, "vt_lstm_create: hidden must be 128, 256 or 384 (got %d): each of the 8 waves owns hidden/8 = whole 16-unit tiles, and 512 "
+                   "would not fit the CU's LDS", d.hidden);
+  if (d.layers < 1 || d.layers > 4 || d.state_dim < 1 || d.state_dim > 16 || d.force_dim < 1 || d.force_dim > KF)
     return vt_fail(VT_ERR_ARG, "vt_lstm_create: bad descriptor (layers 1..4, state_dim <= 16, force_dim <= %d)", KF);
+  if (d.hidden == 384 && d.layers > 3) return vt_fail(VT_ERR_UNSUPPORTED, "vt_lstm_create: hidden 384 with 4 layers does not fit the CU's LDS");
   if (d.cdt != VT_F32 && d.cdt != VT_BF16 && d.cdt != VT_F32X3) return vt_fail(VT_ERR_ARG, "vt_lstm_create: weights must be fp32, split-bf16 (x3) or bf16");
   if (n != vt_lstm_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_lstm_create: expected %d weights, got %d", vt_lstm_num_weights(desc), n);
   for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_lstm_create: weight %d is null", k);
@@ -299,11 +332,18 @@ int vt_lstm_sequence(vt_lstm_t hd, const float* obs_cond, const float* vla_n, co
   p.obs = obs_cond; p.vla = vla_n; p.force = force; p.h = h; p.c = c; p.out = out_n; p.B = B; p.T = T;
   const dim3 grid((B + ROWS - 1) / ROWS);
   const int cdt = hd->d.cdt;
-#define VT_LSTM_GO(NL) do { if (cdt == VT_BF16) hipLaunchKernelGGL((lstm_seq_kernel<bf16_t, NL>), grid, dim3(512), 0, (hipStream_t)stream, p); \
-                            else if (cdt == VT_F32X3) hipLaunchKernelGGL((lstm_seq_kernel<x3w_t, NL>), grid, dim3(512), 0, (hipStream_t)stream, p); \
-                            else hipLaunchKernelGGL((lstm_seq_kernel<float, NL>), grid, dim3(512), 0, (hipStream_t)stream, p); } while (0)
-  switch (hd->d.layers) { case 1: VT_LSTM_GO(1); break; case 2: VT_LSTM_GO(2); break; case 3: VT_LSTM_GO(3); break; default: VT_LSTM_GO(4); break; }
+#define VT_LSTM_GO2(NL, HH) do { if (cdt == VT_BF16) hipLaunchKernelGGL((lstm_seq_kernel<bf16_t, NL, HH>), grid, dim3(512), 0, (hipStream_t)stream, p); \
+                                 else if (cdt == VT_F32X3) hipLaunchKernelGGL((lstm_seq_kernel<x3w_t, NL, HH>), grid, dim3(512), 0, (hipStream_t)stream, p); \
+                                 else hipLaunchKernelGGL((lstm_seq_kernel<float, NL, HH>), grid, dim3(512), 0, (hipStream_t)stream, p); } while (0)
+#define VT_LSTM_GO(NL) do { if (hd->d.hidden == 128) VT_LSTM_GO2(NL, 128); else if (hd->d.hidden == 256) VT_LSTM_GO2(NL, 256); else VT_LSTM_GO2(NL, 384); } while (0)
+  switch (hd->d.layers) {
+    case 1: VT_LSTM_GO(1); break;
+    case 2: VT_LSTM_GO(2); break;
+    case 3: VT_LSTM_GO(3); break;
+    default: if (hd->d.hidden == 128) VT_LSTM_GO2(4, 128); else VT_LSTM_GO2(4, 256); break;      // (384 x 4 layers is rejected at create: LDS)
+  }
 #undef VT_LSTM_GO
+#undef VT_LSTM_GO2
   return vt_check_launch();
 }
 

@@ -34,10 +34,10 @@ class _LSTMParams(ParamModule):
 class TactileLSTMController:
     def __init__(self, state_dim=10, hidden_dim=256, num_layers=2, dropout=0.1, image_model_path="facebook/dinov2-small",
                  device="cuda", force_dim=3, use_force=True, precision: Optional[str] = None, image_state_dict=None):
-        if hidden_dim != 256 or state_dim > 16:
-            # the inference head is ONE persistent kernel per call (csrc/vt_lstm.hip) that deals the 4 x 256 gate rows over its 8 waves;
-            # the reference's default (lstm_step_controller.py:16, --hidden_dim 256) is the only width it is built for
-            raise ValueError(f"TactileLSTMController on MI355X: hidden_dim must be 256 and state_dim <= 16 (got {hidden_dim}, {state_dim})")
+        if hidden_dim not in (128, 256, 384) or state_dim > 16:
+            # the inference head is ONE persistent kernel per call (csrc/vt_lstm.hip) that deals the 4 x hidden gate rows over its 8 waves in whole
+            # 16-unit tiles: hidden_dim 128 / 256 (the reference's default, lstm_step_controller.py:16) / 384
+            raise ValueError(f"TactileLSTMController on MI355X: hidden_dim must be 128, 256 or 384 and state_dim <= 16 (got {hidden_dim}, {state_dim})")
         self.state_dim = state_dim
         self.hidden_dim = hidden_dim
         self.device = device

@@ -533,8 +533,10 @@ class LstmEngine:
         H = hidden
         self.state_dim, self.hidden, self.layers = state_dim, hidden, layers
         fpad, inpad = _pad_to(force_dim), _pad_to(H // 2 + state_dim)
-        if H != 256:
-            raise L.VtError("LstmEngine: hidden_dim must be 256 (the persistent kernel's wave <-> hidden-unit deal)")
+        if H not in (128, 256, 384):
+            raise L.VtError("LstmEngine: hidden_dim must be 128, 256 or 384 (each of the persistent kernel's 8 waves owns hidden/8 = whole 16-unit tiles)")
+        if state_dim > 16:
+            raise L.VtError("LstmEngine: state_dim <= 16")
         g = lambda m, k: mods[m][k].detach().float().cpu()
 
         def pack(w: torch.Tensor, row_starts, kpad: int) -> torch.Tensor:
@@ -555,12 +557,14 @@ class LstmEngine:
             return out.contiguous().to(wdt).to(dev)
 
         seq_tiles = lambda n: [16 * i for i in range(n // 16)]
-        gate_tiles = [q * 256 + 32 * w_ + 16 * t for w_ in range(8) for q in range(4) for t in range(2)]     # tile 8w + 2q + t
+        UT, UW = H // 128, H // 8                   # 16-unit tiles per gate per wave, hidden units per wave
+        gate_tiles = [q * H + UW * w_ + 16 * t for w_ in range(8) for q in range(4) for t in range(UT)]       # tile 4 UT w + UT q + t
+        KX = (H // 2 + 16 + 31) // 32 * 32          # layer-0 input [force features H/2 | vla_n | 0 ...] in whole k-steps (H = 256: 160)
         W = [pack(g("force_encoder", "0.weight"), seq_tiles(H // 2), 32), g("force_encoder", "0.bias").to(dev),
              pack(g("force_encoder", "2.weight"), seq_tiles(H // 2), H // 2), g("force_encoder", "2.bias").to(dev)]
         for l in range(layers):
             wih, whh = g("lstm", f"weight_ih_l{l}"), g("lstm", f"weight_hh_l{l}")
-            kx = 160 if l == 0 else H
+            kx = KX if l == 0 else H
             wcat = torch.zeros(4 * H, kx + H)
             wcat[:, : wih.shape[1]] = wih
             wcat[:, kx:] = whh
