@@ -263,16 +263,8 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nw = blockDim.x >> 6;
   const int g = lane >> 4, l15 = lane & 15;
-  // 1-D grid of (query block, head, batch) with the query block fastest, XCD-swizzled: workgroups are dealt round-robin over the 8 XCDs, so block
-  // id -> (id % 8) * (total / 8) + id / 8 puts CONSECUTIVE work items on ONE XCD — the query blocks of a (batch, head) then share its K / V rows in that
-  // XCD's L2 instead of each pulling them through the fabric (SigLIP: 6 query blocks x 233 KB per (image, head): 4.3 GB per layer down to 0.7)
-  const int qblocks = (p.Nq + nw * 16 - 1) / (nw * 16);
-  const int total = gridDim.x;
-  int wid = blockIdx.x;
-  if ((total & 7) == 0) wid = (wid & 7) * (total >> 3) + (wid >> 3);
-  const int qb = wid % qblocks;
-  const int h = (wid / qblocks) % p.H, b = wid / (qblocks * p.H);
-  const int q = qb * (nw * 16) + wave * 16 + l15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
   const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
   const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
   const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
@@ -456,10 +448,9 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
   static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 1; }();
   if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
-    const dim3 grid1(grid.x * grid.y * grid.z);       // (query block, head, batch) decoded in the kernel, XCD-swizzled
-#define VT_A16(T) do { if (p.hd == 96) hipLaunchKernelGGL((attn16_kernel<T, 96>), grid1, dim3(64 * nw), 0, s, p); \
-                       else if (p.hd == 80) hipLaunchKernelGGL((attn16_kernel<T, 80>), grid1, dim3(64 * nw), 0, s, p); \
-                       else hipLaunchKernelGGL((attn16_kernel<T, 64>), grid1, dim3(64 * nw), 0, s, p); } while (0)
+#define VT_A16(T) do { if (p.hd == 96) hipLaunchKernelGGL((attn16_kernel<T, 96>), grid, dim3(64 * nw), 0, s, p); \
+                       else if (p.hd == 80) hipLaunchKernelGGL((attn16_kernel<T, 80>), grid, dim3(64 * nw), 0, s, p); \
+                       else hipLaunchKernelGGL((attn16_kernel<T, 64>), grid, dim3(64 * nw), 0, s, p); } while (0)
     if (p.dtype == VT_BF16) VT_A16(bf16_t); else VT_A16(half_t);
 #undef VT_A16
     return vt_check_launch();
