@@ -58,7 +58,7 @@ def parse():
                     help="batches in flight per GPU: consecutive steps (independent batches of --batch episodes) are enqueued round-robin on this "
                          "many HIP streams, each with its own workspaces and hipGraph, so the launch-bound phases of one batch (pi_I U-Nets, the "
                          "small per-denoise-step RDT launches) run beside the MFMA-bound phases of another.  1 = one batch at a time (latency "
-                         "mode).  0 = the default of the workload (full / rdt / pi_refine / lstm: 2, else 1)")
+                         "mode).  0 = the default of the workload (full / rdt / pi_refine / lstm: 3, robot: 2, else 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", dest="no_overlap", action="store_false", default=True,
                     help="run the observation encoding on a second HIP stream beside the RDT chunk generation (measured: <1 %% gain)")
@@ -147,7 +147,9 @@ def main():
     setup_s = time.time() - t0
     B, T = args.batch, args.horizon
     inp = synth_inputs(B, T, args.res, 1234 + rank, dev)
-    n_streams = args.streams if args.streams > 0 else (2 if args.workload in ("full", "rdt", "pi_refine", "lstm", "robot") else 1)
+    # batches in flight by default: 3 for the RDT / pi_I workloads (round 4, measured on one box: full 410 -> 422 chunks/s, rdt 459 -> 464, pi_refine 4 277 -> 4 536,
+    # lstm 6 952 -> 7 342; 4 in flight: 404), 2 for `robot` (137 vs 134 with 3), 1 for the rest
+    n_streams = args.streams if args.streams > 0 else (3 if args.workload in ("full", "rdt", "pi_refine", "lstm") else (2 if args.workload == "robot" else 1))
     noise_bufs = [torch.empty(10, B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
     out_holders = [{} for _ in range(n_streams)]
     vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]

@@ -128,8 +128,8 @@ def test_two_streams_in_flight_are_bit_identical_to_one(rdt1b):
             assert torch.equal(o, ref_pi)
 
 
-def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b):
-    """bench.py's headline mode, exactly: two captured hipGraphs of the WHOLE step at B = 32 (RDT-1B chunk -> first 16 ticks x 10 EEF dims ->
+def test_bench_pattern_full_graphs_in_flight_are_bit_identical_to_one(rdt1b):
+    """bench.py's headline mode, exactly: three (round 4's default; two before) captured hipGraphs of the WHOLE step at B = 32 (RDT-1B chunk -> first 16 ticks x 10 EEF dims ->
     DINOv2-B x2 + MLP + 10-step SDE), one per HIP stream, replayed alternately so that two full steps are always in flight (RDT beside RDT,
     K|V projections beside denoise-loop tiles beside the fused U-Net launches).  With the start noise and the SDE noise held fixed every
     replay on either stream must reproduce the one-at-a-time result bit for bit (VERDICT r3 weak #3)."""
@@ -144,8 +144,9 @@ def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b)
     z = mk(g.standard_normal((10, B, T, 10)))
     d = rdt_inputs(B, seed=11)
     x0 = d["x0"]                                        # bf16-rounded values in fp32, what bench.py's device RNG hands over
-    vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=DEV) for _ in range(2)]
-    hold = [{}, {}]
+    NS = 3
+    vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=DEV) for _ in range(NS)]
+    hold = [{} for _ in range(NS)]
 
     def step(si):
         chunk = rdt1b.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=x0, return_fp32=True)
@@ -153,7 +154,7 @@ def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b)
         hold[si]["chunk"] = chunk
         hold[si]["out"] = ctrl.predict(state, vla, cam1, cam2, forces, noise=z)
 
-    streams = [torch.cuda.Stream(device=DEV) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(NS)]
     with torch.cuda.stream(streams[0]):                 # the one-at-a-time reference (eager, nothing beside it)
         step(0)
         streams[0].synchronize()
@@ -175,7 +176,7 @@ def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b)
                 graphs[si].replay()
         # results of round `rnd` are read after both streams drain; the NEXT round is enqueued behind them, so two steps overlap fully
         torch.cuda.synchronize()
-        for si in range(2):
+        for si in range(NS):
             assert torch.equal(hold[si]["chunk"], ref_chunk), (rnd, si, float((hold[si]["chunk"] - ref_chunk).abs().max()))
             assert torch.equal(hold[si]["out"], ref_out), (rnd, si, float((hold[si]["out"] - ref_out).abs().max()))
     # and back to back without a host sync in between (the bench's steady state: step i+2 queued behind step i on the same stream)
@@ -184,7 +185,7 @@ def test_bench_pattern_two_full_graphs_in_flight_are_bit_identical_to_one(rdt1b)
             with torch.cuda.stream(st):
                 graphs[si].replay()
     torch.cuda.synchronize()
-    for si in range(2):
+    for si in range(NS):
         assert torch.equal(hold[si]["chunk"], ref_chunk) and torch.equal(hold[si]["out"], ref_out)
 
 

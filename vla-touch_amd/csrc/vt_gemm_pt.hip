@@ -157,7 +157,7 @@ struct TileId { int m0, n0; };
 // count the tiles of ONE role (KV: one half of the columns); `nroles` = 2 for the KV kind: blocks with ((blockIdx.x >> 3) & 1) == 1 are the V role.
 template <typename T16, int KIND, int ACT, bool SWAP>
 __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int nroles,
-                                        const int abl) {
+                                        const int abl, const bool rev = false) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;          // group (row half), column quarter
@@ -177,10 +177,11 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
   const int band0 = banded ? (bx & 7) * band : 0;
   const int bandn = min(band, total_tiles - band0);                 // may be <= 0 for the last XCDs of a tiny grid
   int idx = banded ? (bx >> 3) : bx;
+  if (rev) idx = S - 1 - idx;       // second phase of a two-phase walk: the blocks that had one tile more in the first phase get one less here
   if (idx >= bandn) return;
 #ifdef VLATOUCH_BENCH_BUILD      // 2 = only the K-role blocks run, 4 = only the V-role blocks (KV kind: how long does each role take alone?)
   if ((abl & 2) && SWAP) return;
-  if ((abl & 4) && !SWAP && nroles == 2) return;
+  if ((abl & 4) && !SWAP && KIND == KIND_KV) return;
 #endif
   auto decode = [&](int id) __attribute__((always_inline)) -> TileId {
     const int sr = id / (GM * tiles_n);
@@ -611,8 +612,17 @@ template <typename T16, int KIND, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_pt_kernel(const VtGemmParams p, const int tiles_n, const int tiles_m, const int total_tiles, const int GM, const int abl) {
   __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];
   if constexpr (KIND == KIND_KV) {
-    if ((blockIdx.x >> ((abl >> 8) & 15)) & 1) pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
-    else pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
+    if (abl & (1 << 12)) {        // A/B (VLATOUCH_PT_KV_SPLIT=1): the first form — K-half and V-half tiles walked by DIFFERENT blocks (alternate groups of 8)
+      if ((blockIdx.x >> ((abl >> 8) & 15)) & 1) pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
+      else pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 2, abl);
+    } else {
+      // every block walks its share of the K-half tiles, then of the V-half tiles (the operand swap is compile time, so the two walks are two copies
+      // of the loop nest): all blocks of an XCD are in the same half at the same time and at the same pace, so the A panel and the W band they share stay
+      // shared, and no CU idles while the slower half finishes.  The second walk takes the slots in reverse, which evens out the odd tile.
+      pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1, abl, false);
+      __syncthreads();            // (LDS of the first walk is dead: its last parameter reads are behind this barrier)
+      pt_body<T16, KIND, ACT, true>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1, abl, true);
+    }
   } else {
     pt_body<T16, KIND, ACT, false>(p, smem, tiles_n, tiles_m, total_tiles, GM, 1, abl);
   }
@@ -673,12 +683,18 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   // measured 1 812 us at 4, 1 831 at 8, 1 864 at 16 on the K|V shape); the other kinds keep 8
   const int gm = g_vt_gm > 0 ? g_vt_gm : (kv ? 4 : 8);
   int grid;
-  if (kv) {                                            // two roles: a multiple of 16 blocks, each role at most `total` blocks
+  static const int kv_split = [] { const char* e = getenv("VLATOUCH_PT_KV_SPLIT"); return e ? atoi(e) : 1; }();
+  if (kv) {
     static const int kv_grid = [] { const char* e = getenv("VLATOUCH_PT_KV_GRID"); return e ? atoi(e) : 0; }();   // A/B: leave CUs to a co-running stream
     const int cap = kv_grid > 0 && kv_grid < g_pt_cus ? kv_grid : g_pt_cus;
-    grid = 2 * total < cap ? 2 * total : cap;
-    grid &= ~255;                                      // (role bit up to 7: whole groups of 256 blocks)
-    if (grid < 256) return VT_ERR_UNSUPPORTED;
+    if (kv_split) {                                    // two roles: whole groups of 256 blocks (role bit up to 7)
+      grid = 2 * total < cap ? 2 * total : cap;
+      grid &= ~255;
+      if (grid < 256) return VT_ERR_UNSUPPORTED;
+    } else {                                           // every block walks both halves: one block per CU, XCD-banded
+      grid = total < cap ? total : cap;
+      if (grid >= 8) grid &= ~7;
+    }
   } else {
     // one block per tile when the tiles fit the chip (195 tiles must not become 192 blocks + a second round for 3 of them: the kernel falls back to the
     // plain tile order when the grid is not a multiple of 8); otherwise one block per CU, XCD-banded
@@ -690,7 +706,7 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
 #endif
   // bits 8..11 of the last argument: which bit of blockIdx.x selects the role of a KV-kind block (3 .. 7; VLATOUCH_PT_ROLE_BIT for A/B)
   static const int role_bit = [] { const char* e = getenv("VLATOUCH_PT_ROLE_BIT"); const int v = e ? atoi(e) : 3; return v >= 3 && v <= 7 ? v : 3; }();
-#define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8))
+#define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8) | (kv_split ? (1 << 12) : 0))
   if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
   else if (p.c_dtype == VT_F32) { if (p.a_dtype == VT_BF16) VT_PT_GO(bf16_t, KIND_R32, VT_ACT_NONE); else VT_PT_GO(half_t, KIND_R32, VT_ACT_NONE); }
   else if (p.a_dtype == VT_BF16) {
