@@ -683,14 +683,16 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   // measured 1 812 us at 4, 1 831 at 8, 1 864 at 16 on the K|V shape); the other kinds keep 8
   const int gm = g_vt_gm > 0 ? g_vt_gm : (kv ? 4 : 8);
   int grid;
+  // bits 8..11 of the last argument: which bit of blockIdx.x selects the role of a KV-kind block (3 .. 7; VLATOUCH_PT_ROLE_BIT for A/B)
+  static const int role_bit = [] { const char* e = getenv("VLATOUCH_PT_ROLE_BIT"); const int v = e ? atoi(e) : 3; return v >= 3 && v <= 7 ? v : 3; }();
   static const int kv_split = [] { const char* e = getenv("VLATOUCH_PT_KV_SPLIT"); return e ? atoi(e) : 1; }();
   if (kv) {
     static const int kv_grid = [] { const char* e = getenv("VLATOUCH_PT_KV_GRID"); return e ? atoi(e) : 0; }();   // A/B: leave CUs to a co-running stream
     const int cap = kv_grid > 0 && kv_grid < g_pt_cus ? kv_grid : g_pt_cus;
     if (kv_split) {                                    // two roles: whole groups of 256 blocks (role bit up to 7)
       grid = 2 * total < cap ? 2 * total : cap;
-      grid &= ~255;
-      if (grid < 256) return VT_ERR_UNSUPPORTED;
+      grid &= ~((2 << role_bit) - 1);                  // whole groups of 2^(role_bit + 1) blocks: 16 for the default bit 3
+      if (grid < (2 << role_bit)) return VT_ERR_UNSUPPORTED;
     } else {                                           // every block walks both halves: one block per CU, XCD-banded
       grid = total < cap ? total : cap;
       if (grid >= 8) grid &= ~7;
@@ -704,8 +706,6 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
 #ifdef VLATOUCH_BENCH_BUILD
   { const char* e = getenv("VLATOUCH_PT_ABL"); g_pt_abl = e ? atoi(e) : 0; }
 #endif
-  // bits 8..11 of the last argument: which bit of blockIdx.x selects the role of a KV-kind block (3 .. 7; VLATOUCH_PT_ROLE_BIT for A/B)
-  static const int role_bit = [] { const char* e = getenv("VLATOUCH_PT_ROLE_BIT"); const int v = e ? atoi(e) : 3; return v >= 3 && v <= 7 ? v : 3; }();
 #define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8) | (kv_split ? (1 << 12) : 0))
   if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
   else if (p.c_dtype == VT_F32) { if (p.a_dtype == VT_BF16) VT_PT_GO(bf16_t, KIND_R32, VT_ACT_NONE); else VT_PT_GO(half_t, KIND_R32, VT_ACT_NONE); }
