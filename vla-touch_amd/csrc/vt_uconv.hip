@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
 
   // ------------------------------------------------------------------ prologue: resolve the input slice
   const int c_abs = slice * cs;
-  const USrc S = c_abs >= p.c_split ? p.src[1] : p.src[0];     // by value: fields live in SGPRs instead of kernarg loads inside the loops
+  const USrc& S = c_abs >= p.c_split ? p.src[1] : p.src[0];    // by reference: the 200-byte descriptor copied into SGPRs cost 62 spills to VGPR lanes; the fields it needs are scalar loads from the kernarg segment
   const int c0 = c_abs >= p.c_split ? c_abs - p.c_split : c_abs;
   const int Tin = p.Tin, c4n = cs >> 2;
   const int c4sh = __builtin_ctz(c4n);                                    // cs = 32 << i
