@@ -239,6 +239,13 @@ template <> __device__ __forceinline__ void mma16_k16<half_t>(float4_t& acc, con
   acc = __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(half4v_t, a), __builtin_bit_cast(half4v_t, b), acc, 0, 0, 0);
 }
 
+#ifdef VLATOUCH_BENCH_BUILD      // timing-only ablations of attn16_kernel (tools/attn_abl.sh; garbage results): 1 = no softmax arithmetic, 2 = no P V, 4 = no Q K^T, 8 = no K / V staging after the first tiles
+__device__ int d_attn_abl = 0;
+#define VT_ATTN_ABL(bit) (d_attn_abl & (bit))
+#else
+#define VT_ATTN_ABL(bit) 0
+#endif
+
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   static_assert(sizeof(T) == 2, "16-bit types only");
@@ -333,7 +340,7 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    if (tile + 2 < ntiles) stage(slot == 0 ? 2 : slot - 1, tile + 2);
+    if (tile + 2 < ntiles && !VT_ATTN_ABL(8)) stage(slot == 0 ? 2 : slot - 1, tile + 2);
     const char* Ks = smem + slot * STAGE;
     const char* Vs = Ks + TILE;
     slot = slot == NST - 1 ? 0 : slot + 1;
@@ -342,6 +349,8 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
 #pragma unroll
     for (int kt = 0; kt < 4; ++kt) {
       sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      tacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      if (VT_ATTN_ABL(4)) continue;
       const int row = kt * 16 + l15;
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
@@ -371,6 +380,7 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
         for (int r = 0; r < 4; ++r)
           if (key0 + kt * 16 + g * 4 + r >= p.Nk) sv[kt * 4 + r] = -INFINITY;
     }
+    if (!VT_ATTN_ABL(1)) {
     float mx = sv[0];
 #pragma unroll
     for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
@@ -391,8 +401,10 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
     l_run += psum;
+    } else { l_run = 1.f; }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      if (VT_ATTN_ABL(2)) break;
       float pj[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) pj[j] = sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)];
@@ -434,6 +446,9 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
+#ifdef VLATOUCH_BENCH_BUILD
+  { const char* e = getenv("VLATOUCH_ATTN_ABL"); const int v = e ? atoi(e) : 0; (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(d_attn_abl), &v, sizeof(int), 0, hipMemcpyHostToDevice, s); }
+#endif
   if (p.dtype != VT_F32 && p.dtype != VT_BF16 && p.dtype != VT_F16) return VT_ERR_UNSUPPORTED;
   const int epc = p.dtype == VT_F32 ? 4 : 8;
   if (p.q_rs % epc || p.k_rs % epc || p.v_rs % epc || p.q_hs % epc || p.k_hs % epc || p.v_hs % epc) return VT_ERR_ARG;
