@@ -9,6 +9,7 @@ except Exception as e: print("$name FAILED", e)
 P
 }
 run full_n1
+run full_streams2_n1 --streams 2 --no-cpu-baseline
 run full_streams1_n1 --streams 1 --no-cpu-baseline
 run pi_refine_n1 --workload pi_refine --no-cpu-baseline
 run pi_refine_streams1_n1 --workload pi_refine --no-cpu-baseline --streams 1
