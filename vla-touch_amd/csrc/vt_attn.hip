@@ -442,6 +442,256 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
   }
 }
 
+
+// ---- attn16u_kernel: attn16_kernel with the tile loop unrolled over the three ring slots.  With the slot a compile-time constant every LDS
+// address of the tile is (per-lane offset computed ONCE before the loop) + (immediate): the 60 address instructions per tile of attn16_kernel
+// (a third of its VALU issue slots; the kernel is VALU-issue-bound in its arithmetic, tools/attn_abl.sh) disappear.  The DMA source addresses
+// are (uniform tile base, SALU) + (per-lane piece offset, computed once) except in the last, clamped tile, and the first two stages are issued
+// BEFORE the Q fragments are loaded so that a block pays one memory round trip before its first MFMA, not two.
+template <int I> struct IC { static constexpr int value = I; };
+
+template <typename T, int HD>
+__global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int KT = 64;
+  constexpr int NKS = HD / 32, NDT = HD / 16;
+  constexpr bool TAIL16 = (HD % 32) == 16;
+  constexpr int TW = (HD - 64) * 2;
+  constexpr int MAINB = KT * 128;
+  constexpr int TILE = MAINB + KT * TW;
+  constexpr int STAGE = 2 * TILE;
+  constexpr int NST = 3;
+  constexpr int TP = KT * TW / 1024;
+  constexpr int PT = 8 + TP;
+  constexpr int PIECES = 2 * PT;
+  constexpr int MAXP = (PIECES + 3) / 4;              // pieces per wave at the smallest block (4 waves)
+  constexpr int CPR = TW > 0 ? TW / 16 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * (nw * 16) + wave * 16 + l15;
+  const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
+  const int ntiles = (p.Nk + KT - 1) / KT;
+
+  // DMA plan (as attn16_kernel): the PIECES 1-KiB pieces of a stage are dealt round-robin over the waves.  poff[n] = this lane's element offset
+  // inside the K (or V) rows of a tile for the wave's n-th piece.
+  const int my_pieces = (PIECES - wave + nw - 1) / nw;
+  unsigned poff[MAXP];
+#pragma unroll
+  for (int n = 0; n < MAXP; ++n) {
+    const int i = wave + n * nw;
+    const bool isv = i >= PT;
+    const int j = isv ? i - PT : i;
+    const unsigned rs = (unsigned)(isv ? p.v_rs : p.k_rs);
+    if (TP == 0 || j < 8) {
+      const int r = j * 8 + (lane >> 3);
+      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 8);
+    } else {
+      const int r = (j - 8) * (64 / CPR) + lane / CPR;
+      poff[n] = (unsigned)r * rs + 64u + (unsigned)((lane % CPR) * 8);
+    }
+  }
+  auto piece_dst = [&](const int slot, const int i) __attribute__((always_inline)) -> char* {
+    const bool isv = i >= PT;
+    const int j = isv ? i - PT : i;
+    return smem + slot * STAGE + (isv ? TILE : 0) + ((TP == 0 || j < 8) ? j * 1024 : MAINB + (j - 8) * 1024);
+  };
+  auto stage = [&](const int slot, const int tile) __attribute__((always_inline)) {
+    const int key0 = tile * KT;
+    if (key0 + KT <= p.Nk) {                          // whole tile: uniform base + per-lane piece offset
+      const T* kb = K + (long)key0 * p.k_rs;
+      const T* vb = V + (long)key0 * p.v_rs;
+#pragma unroll
+      for (int n = 0; n < MAXP; ++n) {
+        const int i = wave + n * nw;
+        if (i < PIECES)
+          __builtin_amdgcn_global_load_lds((glb_void_a*)((i >= PT ? vb : kb) + poff[n]), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+      }
+    } else {                                          // last tile: rows clamped to the last key (masked in the softmax)
+      for (int i = wave; i < PIECES; i += nw) {
+        const bool isv = i >= PT;
+        const int j = isv ? i - PT : i;
+        const T* base = isv ? V : K;
+        const long rs = isv ? p.v_rs : p.k_rs;
+        if (TP == 0 || j < 8) {
+          const int r = j * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ ((r >> 1) & 7);
+          __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+        } else {
+          const int r = (j - 8) * (64 / CPR) + lane / CPR;
+          const int c = lane % CPR;
+          __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + 64 + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+        }
+      }
+    }
+  };
+  auto wait_own = [&](const bool younger_in_flight) __attribute__((always_inline)) {
+    if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // first two stages, THEN the Q fragments; everything retired together (an ordinary load pending beside LDS-DMA makes hipcc drain the whole
+  // queue at its first use anyway)
+  stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  Frag<T> qf[NKS];
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) QLoad<T>::ld(qf[ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+  short4_t q16 = {0, 0, 0, 0};
+  if constexpr (TAIL16) { if (q < p.Nq) q16 = *reinterpret_cast<const short4_t*>(Q + (long)q * p.q_rs + NKS * 32 + g * 4); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].v));
+  asm volatile("" : "+v"(q16));
+
+  // per-lane LDS offsets inside a tile (see attn16_kernel for the fragment conventions)
+  //   K fragment (key row kt*16 + l15, 16-byte chunk ks*4 + g, swizzled by (row >> 1) & 7 = (l15 >> 1) & 7):  kt*2048 + koff[ks]
+  //   V fragment (key kb*32 + hh*16 + vkey, d columns dt*16 + (l15 & 3)*4 ..):  (kb*32 + hh*16)*128 + voff[dt]   (dt < 4)
+  const int ksw = (l15 >> 1) & 7;
+  unsigned koff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) koff[ks] = (unsigned)(l15 * 128 + (((ks * 4 + g) ^ ksw) * 16));
+  const unsigned ktail = (unsigned)(MAINB + l15 * TW + g * 16);          // + kt*16*TW + (ks-2)*64; the 16-deep tail step reads ... + g*8 instead
+  const unsigned ktail16 = (unsigned)(MAINB + l15 * TW + (NKS - 2) * 64 + g * 8);
+  const int vkey = g * 4 + (l15 >> 2);
+  const int vsw = ((vkey >> 1) & 7) ^ ((l15 & 3) >> 1);
+  unsigned voff[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) voff[dt] = (unsigned)(vkey * 128 + (((dt * 2) ^ vsw) * 16) + (l15 & 1) * 8);
+  const unsigned vtail = (unsigned)(MAINB + vkey * TW + (l15 & 3) * 8);  // + (kb*32 + hh*16)*TW + (dt-4)*32
+#pragma unroll
+  for (int i = 0; i < 2; ++i) asm volatile("" : "+v"(koff[i]));
+#pragma unroll
+  for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(voff[i]));
+
+  float4_t o[NDT];
+#pragma unroll
+  for (int i = 0; i < NDT; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+  const float cscale = p.scale * 1.4426950408889634f;
+
+  auto body = [&](auto slot_c, const int tile) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_c)::value;
+    constexpr int NEXT = SLOT == 0 ? 2 : SLOT - 1;      // the slot tile t-1 used: free after this tile's barrier
+    const int key0 = tile * KT;
+    wait_own(tile + 1 < ntiles);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 2 < ntiles && !VT_ATTN_ABL(8)) stage(NEXT, tile + 2);
+    const char* Ks = smem + SLOT * STAGE;
+    const char* Vs = Ks + TILE;
+
+    float4_t sacc[4], tacc[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      tacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      if (VT_ATTN_ABL(4)) continue;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        Frag<T> kf;
+        if (ks < 2) kf.v = *reinterpret_cast<const short8_t*>(Ks + kt * 2048 + koff[ks]);
+        else kf.v = *reinterpret_cast<const short8_t*>(Ks + kt * 16 * TW + (ks - 2) * 64 + ktail);
+        mma16(sacc[kt], kf, qf[ks]);
+      }
+      if constexpr (TAIL16) {
+        // own accumulator, added on the VALU below (the SrcC hazard between the 8-pass and 4-pass MFMAs, see attn16_kernel)
+        const short4_t k16 = *reinterpret_cast<const short4_t*>(Ks + kt * 16 * TW + ktail16);
+        mma16_k16<T>(tacc[kt], k16, q16);
+      }
+    }
+    float sv[16];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = TAIL16 ? sacc[kt][r] + tacc[kt][r] : sacc[kt][r];
+    if (key0 + KT > p.Nk) {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (key0 + kt * 16 + g * 4 + r >= p.Nk) sv[kt * 4 + r] = -INFINITY;
+    }
+    if (!VT_ATTN_ABL(1)) {
+      float mx = sv[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      if (__any(m_new != m_run)) {
+        const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
+        l_run *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[dt][r] *= alpha;
+        m_run = m_new;
+      }
+      const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+      l_run += psum;
+    } else { l_run = 1.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (VT_ATTN_ABL(2)) break;
+      float pj[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) pj[j] = sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)];
+      Frag<T> pf;
+      PackP<T>::pack(pf, pj);
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        Frag<T> vf;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const char* a = dt < 4 ? Vs + (kb * 32 + hh * 16) * 128 + voff[dt < 4 ? dt : 0]
+                                 : Vs + (kb * 32 + hh * 16) * TW + (dt - 4) * 32 + vtail;
+          const short4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a);
+          vf.v[hh * 4 + 0] = t[0]; vf.v[hh * 4 + 1] = t[1]; vf.v[hh * 4 + 2] = t[2]; vf.v[hh * 4 + 3] = t[3];
+        }
+        mma16(o[dt], vf, pf);
+      }
+    }
+  };
+
+  for (int tile = 0; tile < ntiles; tile += 3) {
+    body(IC<0>{}, tile);
+    if (tile + 1 >= ntiles) break;
+    body(IC<1>{}, tile + 1);
+    if (tile + 2 >= ntiles) break;
+    body(IC<2>{}, tile + 2);
+  }
+
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  const float inv = 1.0f / l;
+  if (q < p.Nq) {
+    T* O = reinterpret_cast<T*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      T ov[4] = {Elem<T>::from_f(o[dt][0] * inv), Elem<T>::from_f(o[dt][1] * inv), Elem<T>::from_f(o[dt][2] * inv), Elem<T>::from_f(o[dt][3] * inv)};
+      *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = *reinterpret_cast<const uint2*>(ov);
+    }
+  }
+}
+
 }  // namespace
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
@@ -461,12 +711,13 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   dim3 grid((p.Nq + rows - 1) / rows, p.H, p.B);
   if (p.hd != 0 && p.hd != 64 && p.hd != 96 && p.hd != 80) return VT_ERR_UNSUPPORTED;
   // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
-  static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 1; }();
+  static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 2; }();
   if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
-#define VT_A16(T) do { if (p.hd == 96) hipLaunchKernelGGL((attn16_kernel<T, 96>), grid, dim3(64 * nw), 0, s, p); \
-                       else if (p.hd == 80) hipLaunchKernelGGL((attn16_kernel<T, 80>), grid, dim3(64 * nw), 0, s, p); \
-                       else hipLaunchKernelGGL((attn16_kernel<T, 64>), grid, dim3(64 * nw), 0, s, p); } while (0)
-    if (p.dtype == VT_BF16) VT_A16(bf16_t); else VT_A16(half_t);
+#define VT_A16(KERN, T) do { if (p.hd == 96) hipLaunchKernelGGL((KERN<T, 96>), grid, dim3(64 * nw), 0, s, p); \
+                       else if (p.hd == 80) hipLaunchKernelGGL((KERN<T, 80>), grid, dim3(64 * nw), 0, s, p); \
+                       else hipLaunchKernelGGL((KERN<T, 64>), grid, dim3(64 * nw), 0, s, p); } while (0)
+    if (a16 == 2) { if (p.dtype == VT_BF16) VT_A16(attn16u_kernel, bf16_t); else VT_A16(attn16u_kernel, half_t); }
+    else { if (p.dtype == VT_BF16) VT_A16(attn16_kernel, bf16_t); else VT_A16(attn16_kernel, half_t); }
 #undef VT_A16
     return vt_check_launch();
   }

@@ -464,6 +464,39 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     *reinterpret_cast<uint32_t*>(dst + d * 64 + vt_kpos(t2)) = v;
   }
 }
+// both halves of the tile stream in ONE launch (blockIdx.z: 0 = K rows, 1 = Vt): the body of the two kernels above
+__global__ __launch_bounds__(256) void retile_kv_kernel(const bf16_t* __restrict__ Ksrc, const bf16_t* __restrict__ Vsrc, long ld, bf16_t* __restrict__ KV, int M, int T) {
+  __shared__ bf16_t tile[64][66];
+  const int h = blockIdx.y, t = blockIdx.x, tid = threadIdx.x;
+  if (blockIdx.z == 0) {
+    const bf16_t* src = Ksrc + (long)h * 64;
+    bf16_t* dst = KV + ((long)h * T + t) * 8192;
+    for (int e = tid; e < 64 * 8; e += 256) {
+      const int r = e >> 3, c = e & 7, m = t * 64 + r;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (m < M) v = *reinterpret_cast<const uint4*>(src + (long)m * ld + c * 8);
+      *reinterpret_cast<uint4*>(dst + r * 64 + c * 8) = v;
+    }
+    return;
+  }
+  const int m0 = t * 64;
+  const bf16_t* src = Vsrc + (long)h * 64;
+  for (int e = tid; e < 64 * 8; e += 256) {
+    const int r = e >> 3, c = e & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m0 + r < M) v = *reinterpret_cast<const uint4*>(src + (long)(m0 + r) * ld + c * 8);
+    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tile[c * 8 + j][r] = ve[j];
+  }
+  __syncthreads();
+  bf16_t* dst = KV + ((long)h * T + t) * 8192 + 4096;
+  for (int e = tid; e < 64 * 32; e += 256) {
+    const int d = e >> 5, t2 = (e & 31) * 2;
+    const uint32_t v = (uint32_t)tile[d][t2] | ((uint32_t)tile[d][t2 + 1] << 16);
+    *reinterpret_cast<uint32_t*>(dst + d * 64 + vt_kpos(t2)) = v;
+  }
+}
 
 }  // namespace
 
@@ -517,7 +550,8 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
 
 int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int M, int T, int H, hipStream_t s) {
   if ((long)T * 64 < M || ld % 8) return VT_ERR_ARG;
-  if (Ksrc) hipLaunchKernelGGL(retile_k_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Ksrc, ld, (bf16_t*)KV, M, T);
-  if (Vsrc) hipLaunchKernelGGL(transpose_v_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, M, T);
+  if (Ksrc && Vsrc) hipLaunchKernelGGL(retile_kv_kernel, dim3(T, H, 2), dim3(256), 0, s, (const bf16_t*)Ksrc, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, M, T);
+  else if (Ksrc) hipLaunchKernelGGL(retile_k_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Ksrc, ld, (bf16_t*)KV, M, T);
+  else if (Vsrc) hipLaunchKernelGGL(transpose_v_kernel, dim3(T, H), dim3(256), 0, s, (const bf16_t*)Vsrc, ld, (bf16_t*)KV, M, T);
   return vt_check_launch();
 }

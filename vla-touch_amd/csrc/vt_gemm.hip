@@ -331,6 +331,8 @@ __global__ __launch_bounds__(256, (TM * TN >= 16 ? 2 : 1)) void gemm_kernel(cons
 template <typename TA, typename TW, typename TC>
 int launch_cfg(const VtGemmParams& p, hipStream_t s) {
   const int z = p.groups * p.splitk;
+  static const bool trace = getenv("VLATOUCH_GEMM_TRACE") != nullptr;      // one line per launch of the register-staged kernel (which shapes still land here?)
+  if (trace) fprintf(stderr, "[vt_gemm generic] M=%d N=%d K=%d groups=%d splitk=%d taps=%d a=%d w=%d c=%d act=%d\n", p.M, p.N, p.K, p.groups, p.splitk, p.taps, p.a_dtype, p.w_dtype, p.c_dtype, p.act);
   VtProfScope prof(5, p, s);   // class 5: this register-staged kernel (exact-fp32 / split-bf16 / small-M products; the training step's GEMMs)
   // tile choice: enough 128x128 tiles to fill the chip -> large tile; tiny M -> 32x64; else 64x64
   const long tiles128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * z;

@@ -15,6 +15,7 @@
 #include "vt_common.h"
 #include "vt_kernels.h"
 #include "vt_host.h"
+#include "vt_prof.h"
 #include "../../include/vlatouch.h"
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
@@ -70,7 +71,8 @@ int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_din
 void vt_dino_destroy(vt_dino_t h) { delete h; }
 
 namespace {
-struct DWs { size_t part, flags, apatch, tok, xn, qkv, att, h1, total; };
+constexpr int DINO_SPLITK = 4, DINO_SPLIT_ROWS = 1100;
+struct DWs { size_t part, flags, apatch, tok, xn, qkv, att, h1, slab, slab_bytes, total; };
 DWs dcarve(const vt_dino_s* h, int Bt, int res) {
   const vt_dino_desc& d = h->d;
   const int a = es(d.adt), g = res / d.patch, N = g * g + (d.no_cls ? 0 : 1), D = d.hidden;
@@ -84,6 +86,9 @@ DWs dcarve(const vt_dino_s* h, int Bt, int res) {
   w.qkv = take((size_t)Bt * N * 3 * Da * a);
   w.att = take((size_t)Bt * N * Da * a);
   w.h1 = take((size_t)Bt * N * Dm * a * (d.act == VT_ACT_SWIGLU ? 2 : 1));      // SwiGLU: fc1 produces [x1 | x2]
+  // split-K scratch of fc2 at a few images (batch 1 of the robot loop: 2 x 257 rows): DINO_SPLITK fp32 slabs of [rows][D]
+  w.slab_bytes = (size_t)Bt * N <= DINO_SPLIT_ROWS ? (size_t)DINO_SPLITK * Bt * N * D * 4 : 0;
+  w.slab = take(w.slab_bytes);
   w.total = o;
   return w;
 }
@@ -134,7 +139,19 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
     if (swiglu) CK(vt_wrap(vt_k_swiglu(ws + w.h1, d.adt, N1, rows, Dm, s), "dino swiglu gate"));
     { VtGemmParams p = lin(ws + w.h1, d.adt, N1, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tok_stride, rows, D, Dm, VT_ACT_NONE);
       p.colscale = L.ls2; p.residual = tok; p.ldr = tok_stride;
-      CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2")); }
+      // a few images (2 x 257 rows at batch 1): 108 tiles of 64 x 64 would each walk K = 3072 alone (50 us); DINO_SPLITK slices per tile into fp32
+      // slabs + the slab reduction (bias, LayerScale, residual) take 17
+      if (w.slab_bytes && rows > 64 && (size_t)DINO_SPLITK * rows * D * 4 <= w.slab_bytes && Dm >= 2048 && (Dm / 64) % DINO_SPLITK == 0 && D % 4 == 0 &&
+          !vt_gemm_fast_eligible(p)) {
+        VtGemmParams q = p;
+        q.C = ws + w.slab; q.c_dtype = VT_F32; q.ldc = D; q.splitk = DINO_SPLITK; q.c_slab = (long)rows * D;
+        q.bias = nullptr; q.colscale = nullptr; q.residual = nullptr;
+        CK(vt_wrap(vt_gemm_launch(q, s), "dino fc2 (split)"));
+        CK(vt_wrap(vt_k_slab_reduce((const float*)(ws + w.slab), DINO_SPLITK, q.c_slab, rows, D, p.bias, VT_ACT_NONE, p.colscale, p.residual, p.ldr, p.C, VT_F32,
+                                    tok_stride, nullptr, nullptr, 0, 0, 0.f, 0, s), "dino fc2 (slab reduction)"));
+      } else {
+        CK(vt_wrap(vt_gemm_launch(p, s), "dino fc2"));
+      } }
     return VT_OK;
   };
   static const bool cls_last_on = [] { const char* e = getenv("VLATOUCH_DINO_CLS_LAST"); return !e || atoi(e) != 0; }();

@@ -215,12 +215,15 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
   // (frozen, fragment-packed weights at small M: the split GEMM below runs on vt_gemm_pws.hip in its slab mode — p.Wp travels with q)
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int nk = p.K / 64;
+  // slices per tile on the fragment-packed small-M kernel: at most 4 (8 slices of a K = 2048 Linear finish the GEMM 1 us sooner and cost the
+  // slab reduction 2 us more: batch 1 21.6 -> 21.0 ms; VLATOUCH_RDT_SPLIT_CAP for A/B)
+  static const int split_cap = [] { const char* e = getenv("VLATOUCH_RDT_SPLIT_CAP"); return e && atoi(e) > 0 ? atoi(e) : 4; }();
   int S = (int)(512 / (tiles64 > 0 ? tiles64 : 1));
   if (S > RDT_MAX_SPLITK) S = RDT_MAX_SPLITK;
   if (S > nk / 2) S = nk / 2;
   if (p.Wp && S >= 2) {              // vt_gemm_pws.hip (slab mode) wants a power of two that leaves whole 4-k-tile chunks per slice
     int P = 1;
-    while (P * 2 <= S && P * 2 <= 8 && nk % (P * 2 * 4) == 0) P *= 2;
+    while (P * 2 <= S && P * 2 <= split_cap && nk % (P * 2 * 4) == 0) P *= 2;
     S = P;
   }
   const bool small = c.w.slab_bytes > 0 && !vt_gemm_fast_eligible(p) && p.M <= 512 && p.K >= 512 && (p.K % 64) == 0 && (p.N % 4) == 0 && !p.hn_w0 &&
@@ -311,12 +314,15 @@ int cache_cond(RCtx& c) {
       if (fuse_headnorm(pkv, b.ckn, D, nullptr, D, d.rms_mode)) {
         CK(vt_wrap(vt_gemm_launch(pkv, c.s), "rdt cond kv"));
       } else {
-        VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, c.ws + c.w.tmpA, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
-        VtGemmParams pv = lin(src, d.adt, D, (const char*)b.ckv_w + (size_t)D * D * c.a, d.cdt, D, b.ckv_b + D, c.ws + c.w.tmpB, d.adt, D, c.B * Lc, D, D, VT_ACT_NONE);
-        CK(vt_wrap(vt_gemm_launch(pk, c.s), "rdt cond k"));
-        CK(vt_k_headnorm(c.ws + c.w.tmpA, d.adt, D, d.heads, (long)c.B * Lc, b.ckn, 1e-6f, d.rms_mode, c.s));
-        CK(vt_wrap(vt_gemm_launch(pv, c.s), "rdt cond v"));
-        CK(vt_wrap(vt_k_retile_kv(c.ws + c.w.tmpA, c.ws + c.w.tmpB, D, kv, c.B * Lc, T, d.heads, c.s), "rdt cond retile"));
+        // small condition (the language tokens below 128 rows: batch 1..3): ONE K | V product (N = 2D) on the split-K path of the denoise loop's
+        // Linears, k_norm folded into its slab reduction, row-major [rows][2D] into tmpA; then one retile launch.  (Two 32-row GEMMs walking
+        // K = 2048 on 32 blocks each + head norm + two retile launches were 75 us per layer at batch 1; this is 20.)
+        const int rows = c.B * Lc;
+        VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, c.ws + c.w.tmpA, d.adt, 2 * D, rows, 2 * D, D, VT_ACT_NONE);
+        bool folded = false;
+        CK(rgemm(c, pk, "rdt cond kv (small)", b.ckn, D, nullptr, D, &folded));
+        if (!folded) CK(vt_k_headnorm(c.ws + c.w.tmpA, d.adt, 2 * D, d.heads, (long)rows, b.ckn, 1e-6f, d.rms_mode, c.s));
+        CK(vt_wrap(vt_k_retile_kv(c.ws + c.w.tmpA, c.ws + c.w.tmpA + (size_t)D * c.a, 2 * D, kv, rows, T, d.heads, c.s), "rdt cond retile"));
       }
     } else {
       VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
