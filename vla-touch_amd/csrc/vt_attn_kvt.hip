@@ -198,7 +198,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
 // traffic, no accumulator rescale, no data-dependent branch — 22 of the ~80 VALU instructions per 16 scores go; the row sum of P moves
 // to the matrix pipe (one extra MFMA per 32 keys against a fragment of ones: it sums exactly the bf16 P that multiplies V, and arrives
 // already reduced over all lanes), another 16 VALU adds.  The launcher falls back to the online form when B > 40.
-template <int RING, bool FIXED>
+template <int RING, bool FIXED, int AUX = 0>
 __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParams p) {
   constexpr int HALF = KT * 128;                     // 8 KiB
   __shared__ __attribute__((aligned(16))) char smem[RING * HALF];
@@ -220,16 +220,6 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
     t_last = min(t_last, t_first + per - 1);
   }
 
-  Frag<bf16_t> qf[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
-  // retire the Q loads before the first DMA: an ordinary load still pending when the ring runs would make the compiler drain
-  // the whole queue (vmcnt(0)) at its first use
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[ks].v));
-
   // a half tile = 8 pieces of 1 KiB (8 rows x 128 B); waves 0..3 issue 2 consecutive pieces each
   const int r_in = lane >> 3, pch = lane & 7;
   const int nh = t_first <= t_last ? 2 * (t_last - t_first + 1) : 0;
@@ -241,7 +231,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
       const int i = wave * 2 + e;
       const int r = i * 8 + r_in;
       const int c = pch ^ ((r >> 1) & 7);
-      __builtin_amdgcn_global_load_lds((glb_void*)(hsrc + (long)hh * 4096 + r * 64 + c * 8), (lds_void*)(smem + slot * HALF + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(hsrc + (long)hh * 4096 + r * 64 + c * 8), (lds_void*)(smem + slot * HALF + i * 1024), 16, 0, AUX);
     }
   };
   // wait until half hh has landed (this wave's pieces), leaving the younger halves in flight; then the block-wide barrier
@@ -270,6 +260,16 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
 #pragma unroll
   for (int hh = 0; hh < RING - 1; ++hh)
     if (hh < nh) stage_half(hh, hh);
+  // the Q fragments AFTER the first halves are on their way (one memory round trip before the first MFMA instead of two: the language
+  // layers' launches are one tile long), and everything retired together: an ordinary load still pending when the ring runs would make the
+  // compiler drain the whole queue (vmcnt(0)) at its first use anyway
+  Frag<bf16_t> qf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+    qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(qf[ks].v));
   int slot = 0;                                       // slot of the half being consumed
   auto next_slot = [&](int s_) { return s_ + 1 == RING ? 0 : s_ + 1; };
   auto prev_slot = [&](int s_) { return s_ == 0 ? RING - 1 : s_ - 1; };
@@ -411,16 +411,30 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   const int row = blockIdx.x * 16 + (threadIdx.x >> 4), d4 = (threadIdx.x & 15) * 4;
   if (row >= Nq) return;
   const float* W = part_ws + ((((long)b * H + h) * parts) * rows_pad + row) * 66;
-  float m = -INFINITY;
-  for (int pi = 0; pi < parts; ++pi) m = fmaxf(m, W[(long)pi * rows_pad * 66 + 64]);
-  float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int pi = 0; pi < parts; ++pi) {
-    const float* Wp = W + (long)pi * rows_pad * 66;
-    const float mp = Wp[64];
-    const float f = (mp == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mp - m) * cscale);
-    l += f * Wp[65];
+  // every part's (m, l, o[4]) in ONE round of loads (parts <= 16, checked by the launcher): the partials were written by blocks on other XCDs, a
+  // dependent second pass over them costs a second fabric round trip (the two-pass form of this loop: 9.2 us per call at batch 1)
+  float mp[16], lp[16];
+  float2 oa[16], ob[16];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] += f * Wp[d4 + r];
+  for (int pi = 0; pi < 16; ++pi) {
+    mp[pi] = -INFINITY; lp[pi] = 0.f; oa[pi] = make_float2(0.f, 0.f); ob[pi] = make_float2(0.f, 0.f);
+    if (pi < parts) {
+      const float* Wp = W + (long)pi * rows_pad * 66;
+      const float2 ml = *reinterpret_cast<const float2*>(Wp + 64);
+      mp[pi] = ml.x; lp[pi] = ml.y;
+      oa[pi] = *reinterpret_cast<const float2*>(Wp + d4);
+      ob[pi] = *reinterpret_cast<const float2*>(Wp + d4 + 2);
+    }
+  }
+  float m = -INFINITY;
+#pragma unroll
+  for (int pi = 0; pi < 16; ++pi) m = fmaxf(m, mp[pi]);
+  float l = 0.f, acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int pi = 0; pi < 16; ++pi) {                 // part order: the same sums as the two-pass loop
+    const float f = (mp[pi] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((mp[pi] - m) * cscale);
+    l += f * lp[pi];
+    acc[0] += f * oa[pi].x; acc[1] += f * oa[pi].y; acc[2] += f * ob[pi].x; acc[3] += f * ob[pi].y;
   }
   const float inv = 1.0f / l;
   uint2 t;
@@ -529,14 +543,19 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   // A/B: extra (unused) dynamic LDS per block lowers the blocks per CU from 4 (4 x 40 KiB = the whole CU) so that a GEMM block of the other in-flight
   // batch can share the CU (VLATOUCH_ATTN_LDS_PAD bytes: 13000 -> 3 blocks, 40000 -> 2 blocks)
   static const int lds_pad = [] { const char* e = getenv("VLATOUCH_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
+  // nt cache policy (aux = 2) on the K / Vt tile DMA: every tile is read once per launch and the stream (16 GB over the 14 image layers) outlives every
+  // cache — 121 -> 104 us per launch averaged over the layers (62 -> 72 % of the HBM roof), full 423 -> 431 chunks/s; VLATOUCH_KVT_NT=0 for A/B
+  static const int kv_nt = [] { const char* e = getenv("VLATOUCH_KVT_NT"); return e ? atoi(e) : 1; }();
 #define VT_KVT_GO(grid) \
-  do { if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), lds_pad, s, p); \
+  do { if (fixed && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (ring == 5 && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
        else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false>), grid, dim3(64 * nw), lds_pad, s, p); \
        else if (ring == 4) hipLaunchKernelGGL((attn_kvt_ring_kernel<4, false>), grid, dim3(64 * nw), 0, s, p); \
        else if (ring == 3) hipLaunchKernelGGL((attn_kvt_ring_kernel<3, false>), grid, dim3(64 * nw), 0, s, p); \
        else hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p); } while (0)
   if (p.parts > 1) {
-    if (qblocks != 1 || !p.part_ws) return VT_ERR_ARG;
+    if (qblocks != 1 || !p.part_ws || p.parts > 16) return VT_ERR_ARG;
     VT_KVT_GO(dim3(p.parts, p.H, p.B));
     hipLaunchKernelGGL(attn_combine_kernel, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (bf16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
                        p.scale * 1.4426950408889634f);

@@ -42,10 +42,16 @@ template <> __device__ __forceinline__ float16_t mma32s<bf16_t>(const int4_t w, 
 template <> __device__ __forceinline__ float16_t mma32s<half_t>(const int4_t w, const int4_t a, const float16_t c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, w), __builtin_bit_cast(f16x8_t, a), c, 0, 0, 0);
 }
+// (A/B: -DVLATOUCH_PWS_NT puts the nt cache policy on the weight stream — every fragment is read by ONE block per launch)
+#ifdef VLATOUCH_PWS_NT
+#define VT_PWS_POL " nt"
+#else
+#define VT_PWS_POL ""
+#endif
 template <int OFF, bool FIRST>
 __device__ __forceinline__ void pws_wload(int4_t& d, const unsigned voff, const char* sbase) {
-  if constexpr (FIRST) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
-  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+  if constexpr (FIRST) asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" VT_PWS_POL : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" VT_PWS_POL : "=v"(d) : "v"(voff), "s"(sbase), "i"(OFF) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void pws_wait(int4_t (&w)[8]) {

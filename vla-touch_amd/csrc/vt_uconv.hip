@@ -16,6 +16,13 @@
 #include "vt_uconv.h"
 #include "vt_prof.h"
 
+// weight fragments: A/B of the nt cache policy (-DVLATOUCH_UCONV_NT; each fragment is read by the m-tiles of one launch only)
+#ifdef VLATOUCH_UCONV_NT
+#define VT_UCONV_WLD(ptr) __builtin_nontemporal_load(ptr)
+#else
+#define VT_UCONV_WLD(ptr) (*(ptr))
+#endif
+
 namespace {
 
 constexpr int WD = 8;   // weight k-steps in flight per wave (8 x 2 KiB)
@@ -69,7 +76,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
 #pragma unroll
   for (int d = 0; d < WD; ++d) {
     const short8_t* q = wbase + (long)min(d, nsteps - 1) * 128;
-    wh[d] = q[0]; wl[d] = q[64];
+    wh[d] = VT_UCONV_WLD(q); wl[d] = VT_UCONV_WLD(q + 64);
   }
 
   // ------------------------------------------------------------------ prologue: resolve the input slice
@@ -360,7 +367,7 @@ __global__ __launch_bounds__(256) void uconv_kernel(const UConvParams p) {
     for (int d = 0; d < WD; ++d) {
       step(wh[d], wl[d]);
       const short8_t* q = wbase + (long)min(s0 + d + WD, nsteps - 1) * 128;
-      wh[d] = q[0]; wl[d] = q[64];
+      wh[d] = VT_UCONV_WLD(q); wl[d] = VT_UCONV_WLD(q + 64);
     }
   }
 #pragma unroll
