@@ -364,6 +364,12 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.taps && (p.cin % epc || p.K != p.taps * p.cin)) return VT_ERR_ARG;
   if (p.splitk < 1 || p.groups < 1) return VT_ERR_ARG;
   if (p.splitk > 1 && p.c_dtype != VT_F32) return VT_ERR_ARG;
+  if (p.xn_out || p.rs_part) {        // fused RMSNorm hand-off: only the weights-in-registers tile implements it, and the caller has checked that it takes this shape
+    if (p.groups != 1 || (p.xn_out && (!p.xn_gain || !p.xn_part || p.c_dtype != VT_F32 || !p.residual || p.act != VT_ACT_NONE || p.hn_w0 || p.hn_w1 || p.xn_ld % 4)) ||
+        (p.rs_part && (p.rs_n < 4 || p.rs_n > 32 || p.rs_n % 4)) || !vt_gemm_fast_eligible(p) || !vt_gemm_pw_eligible(p))
+      return VT_ERR_UNSUPPORTED;
+    return vt_gemm_pw_launch(p, s);
+  }
   if (vt_gemm_pws_eligible(p) && (p.M <= 192 || !vt_gemm_fast_eligible(p))) return vt_gemm_pws_launch(p, s);   // small M, frozen packed weights
   if (vt_gemm_fast_eligible(p)) return vt_gemm_fast_launch(p, s);     // large bf16 GEMMs: LDS-DMA pipeline (vt_gemm_fast.hip)
   if (p.hn_w0 || p.hn_w1 || p.cmap) return VT_ERR_UNSUPPORTED;         // fused head-norm / tile-stream output exist only on the fast path

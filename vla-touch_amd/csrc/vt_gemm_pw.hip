@@ -71,7 +71,8 @@ template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
 
 // ABL (timing-only ablations, tools/gemm_bench_pw.py --abl; results are garbage): 1 = no fragment reads after the prologue, 2 = no weight
 // loads after the prologue, 3 = no MFMAs, 4 = no activation DMA after the prologue
-template <typename T16, typename TC, int NB, int ABL = 0>
+// FUSE: 0 = plain, 1 = producer of a fused RMSNorm hand-off (xn_out / xn_part), 2 = its consumer (rs_part) — own instantiations: the plain kernels keep their registers
+template <typename T16, typename TC, int NB, int ABL = 0, int FUSE = 0>
 __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {
   constexpr int SMEM = NB * A_TILE > BM * BN * 4 ? NB * A_TILE : BM * BN * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM];                  // ring of A k-tiles; later the block's fp32 output tile
@@ -154,10 +155,21 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   frags(af[0], 0, 0);
   if constexpr (ABL == 1) frags(af[1], 0, 1);
 
+  float4 rsv[FUSE == 2 ? 8 : 1];
   auto sub = [&](const int t, auto uc, auto tailc) {
     constexpr int U = decltype(uc)::value;
     constexpr bool TAIL = decltype(tailc)::value;
     if constexpr (!TAIL || U == 0) issue(t + NB - 1, std::integral_constant<int, (U + NB - 1) % NB>{});
+    if constexpr (FUSE == 2 && TAIL && U == NB - 2) {
+      // consumer of a fused RMSNorm: the row's sums of squares are requested HERE — behind the last counted wait of the k-loop (the queue is empty, no
+      // later wait counts operations) and two k-tiles ahead of the epilogue that needs them, so neither the start of the k-loop nor its end waits for them
+      if (tid < BM) {
+        const float4* pp = reinterpret_cast<const float4*>(p.rs_part + (long)min(m0 + tid, p.M - 1) * p.rs_n);
+        const int n4 = p.rs_n >> 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rsv[i] = i < n4 ? pp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       if constexpr (ABL != 1) {
@@ -198,6 +210,22 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   // ---------------- epilogue: accumulators -> the block's fp32 tile in LDS [160][128], 16-byte columns XOR-swizzled by the row; read back as
   // row segments: 16 lanes cover 64 columns (= one head) of one row, 4 rows per instruction; wave w takes column half w & 1 of rows (w >> 1) * 80 ..
   float* tile = reinterpret_cast<float*>(smem);
+  float rs[TMW];
+#pragma unroll
+  for (int j = 0; j < TMW; ++j) rs[j] = 1.f;
+  if constexpr (FUSE == 2) {
+    // rstd of the block's 160 rows (one row per thread, fixed summation order), handed to the lanes that own the rows' accumulators through the dead ring
+    if (tid < BM) {
+      float sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sq += (rsv[i].x + rsv[i].y) + (rsv[i].z + rsv[i].w);
+      tile[tid] = rsqrtf(sq * p.rs_inv_k + p.rs_eps);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TMW; ++j) rs[j] = tile[j * 32 + l31];
+    __syncthreads();
+  }
   const int half = wave & 1, c4 = lane & 15;
   const int ncol0 = n0 + half * 64, n = ncol0 + c4 * 4;
   const bool col_ok = n < p.N;
@@ -222,10 +250,12 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
 #pragma unroll
   for (int j = 0; j < TMW; ++j) {
     const int m = j * 32 + l31;
+    const float r = FUSE == 2 ? rs[j] : 1.f;                                  // the rows' rstd when this Linear consumes a fused RMSNorm
 #pragma unroll
     for (int rq = 0; rq < 4; ++rq) {
       const int n4 = wave * 8 + rq * 2 + hk;                                  // 16-byte column of n = wave*32 + rq*8 + hk*4 .. +3
-      *reinterpret_cast<float4*>(tile + m * BN + ((n4 ^ (m & 7)) * 4)) = make_float4(acc[j][rq * 4], acc[j][rq * 4 + 1], acc[j][rq * 4 + 2], acc[j][rq * 4 + 3]);
+      *reinterpret_cast<float4*>(tile + m * BN + ((n4 ^ (m & 7)) * 4)) =
+          make_float4(acc[j][rq * 4] * r, acc[j][rq * 4 + 1] * r, acc[j][rq * 4 + 2] * r, acc[j][rq * 4 + 3] * r);
     }
   }
   __syncthreads();
@@ -243,6 +273,30 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
       const int row = rbase + it * 4;
       const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
       vt_epi_segment<TC, 0, true>(p, x, b4, cs4, hw, hw4, Cg, Rg, m0 + row, n, ncol0, col_ok);
+    }
+  } else if (FUSE == 1 && PRE && use_pre) {
+    // producer of a fused RMSNorm: C = residual + colscale * (product + bias) as below, plus the 16-bit copy C * gain the next Linear reads as its
+    // A operand and the sum of squares of this row over the wave's 64 columns (all 16 lanes of a row segment take part in the reduction)
+    if constexpr (PRE && FUSE == 1) {
+      const float4 g4 = col_ok ? *reinterpret_cast<const float4*>(p.xn_gain + n) : zero4;
+      T16* Xn = reinterpret_cast<T16*>(p.xn_out);
+      const int pcol = 2 * tn + half, pn = 2 * tiles_n;
+#pragma unroll
+      for (int it = 0; it < BM / 8; ++it) {
+        const int row = rbase + it * 4, m = m0 + row;
+        const float4 x = *reinterpret_cast<const float4*>(tile + row * BN + (((half * 16 + c4) ^ (row & 7)) * 4));
+        float o[4] = {x.x + b4.x, x.y + b4.y, x.z + b4.z, x.w + b4.w};
+        o[0] *= cs4.x; o[1] *= cs4.y; o[2] *= cs4.z; o[3] *= cs4.w;
+        o[0] += rpre[it].x; o[1] += rpre[it].y; o[2] += rpre[it].z; o[3] += rpre[it].w;
+        const bool ok = m < p.M && col_ok;
+        const float q = row16_sum(ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f);
+        if (ok) {
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+          T16 ov[4] = {Elem<T16>::from_f(o[0] * g4.x), Elem<T16>::from_f(o[1] * g4.y), Elem<T16>::from_f(o[2] * g4.z), Elem<T16>::from_f(o[3] * g4.w)};
+          *reinterpret_cast<uint2*>(Xn + (long)m * p.xn_ld + n) = *reinterpret_cast<const uint2*>(ov);
+        }
+        if (c4 == 0 && m < p.M) p.xn_part[(long)m * pn + pcol] = q;
+      }
     }
   } else if (use_pre) {
 #pragma unroll
@@ -312,6 +366,22 @@ int vt_gemm_pw_launch(const VtGemmParams& p, hipStream_t s) {
     return vt_check_launch();
   }
 #endif
+  if (p.xn_out || p.rs_part) {        // fused RMSNorm hand-off (vt_gemm.h): ring depth 4 only
+    const dim3 g(total), b(256);
+    if (p.xn_out && (c16 || !p.residual || p.act != VT_ACT_NONE || p.hn_w0 || p.hn_w1)) return VT_ERR_UNSUPPORTED;
+    if (p.xn_out && p.rs_part) return VT_ERR_UNSUPPORTED;
+    if (p.xn_out) {
+      if (p.a_dtype == VT_BF16) hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, float, 4, 0, 1>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+      else hipLaunchKernelGGL((gemm_pw_kernel<half_t, float, 4, 0, 1>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    } else if (!c16) {
+      return VT_ERR_UNSUPPORTED;        // consumers are the 16-bit-output Linears (qkv, cross q, fc1); an fp32-output consumer would need 260 VGPRs (no second block per CU)
+    } else if (p.a_dtype == VT_BF16) {
+      hipLaunchKernelGGL((gemm_pw_kernel<bf16_t, bf16_t, 4, 0, 2>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    } else {
+      hipLaunchKernelGGL((gemm_pw_kernel<half_t, half_t, 4, 0, 2>), g, b, 0, s, p, tiles_n, per_group, total, gm);
+    }
+    return vt_check_launch();
+  }
   if (p.a_dtype == VT_BF16) { if (c16) VT_PW_GO(bf16_t, bf16_t); else VT_PW_GO(bf16_t, float); }
   else { if (c16) VT_PW_GO(half_t, half_t); else VT_PW_GO(half_t, float); }
 #undef VT_PW_GO

@@ -151,7 +151,7 @@ constexpr int RDT_MAX_SPLITK = 16;
 constexpr int RDT_SK_CNT = 4096;
 struct RWs {
   size_t lang_c, img_c, tmpA, tmpB, state_tok, freq_emb, t_emb, emb_tmp, sin, kv_lang, kv_img, x, xn, qkv, q, att, hid, sa_in, sa_tmpA, sa_tmpB,
-      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, sk_cnt, total;
+      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, sk_cnt, rs_part, total;
   size_t kv_lang_blk, kv_img_blk;   // bytes per block
   size_t slab_bytes;                // split-K scratch of the small-batch Linears (0 when M is large enough without it)
   size_t attn_part; int attn_parts; // key-range parts of the cached cross-attention at small batch (1 = off)
@@ -175,6 +175,7 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.kv_lang = take(w.kv_lang_blk * n_lang_blk);
   w.kv_img = take(w.kv_img_blk * n_img_blk);
   const size_t M = (size_t)B * N;
+  w.rs_part = take(M * (2 * (D / 128) + 4) * 4);      // fused RMSNorm hand-off: sums of squares per (row, 64 columns)
   w.x = take(M * D * 4); w.xn = take(M * D * a); w.qkv = take(M * 3 * D * a); w.q = take(M * D * a); w.att = take(M * D * a); w.hid = take(M * D * a);
   w.sa_in = take((size_t)B * d.horizon * 2 * d.state_dim * a);
   w.sa_tmpA = take((size_t)B * d.horizon * D * a); w.sa_tmpB = take((size_t)B * d.horizon * D * a);
@@ -192,7 +193,9 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   return w;
 }
 
-struct RCtx { const vt_rdt_s* h; int B, L; char* ws; RWs w; hipStream_t s; int a; };
+struct RCtx { const vt_rdt_s* h; int B, L; char* ws; RWs w; hipStream_t s; int a;
+              bool fuse_norm = false;     // residual Linears hand the RMSNorm that follows them to the next Linear (vt_gemm.h, xn_out / rs_part)
+              bool rs_pending = false; }; // c.w.xn holds x * gain, un-normalised: the next Linear applies rstd from c.w.rs_part
 
 // request the fused per-head RMSNorm epilogue when this GEMM takes the large-GEMM path; returns false -> caller runs vt_k_headnorm
 bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1, int c1_end, int mode) {
@@ -209,7 +212,7 @@ bool fuse_headnorm(VtGemmParams& p, const float* w0, int c0_end, const float* w1
 // next_norm / xn_done: for a residual Linear into the fp32 stream (C == residual == x, full row width), the RMSNorm that follows it
 // is computed by the slab reduction too (*xn_done = true: c.w.xn holds norm(x) * next_norm).
 int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullptr, int hn_c0 = 0, const float* hn_w1 = nullptr, int hn_c1 = 0,
-          bool* hn_done = nullptr, const float* next_norm = nullptr, bool* xn_done = nullptr) {
+          bool* hn_done = nullptr, const float* next_norm = nullptr, bool* xn_done = nullptr, bool pw_fuse = true) {
   if (hn_done) *hn_done = false;
   if (xn_done) *xn_done = false;
   // (frozen, fragment-packed weights at small M: the split GEMM below runs on vt_gemm_pws.hip in its slab mode — p.Wp travels with q)
@@ -228,7 +231,14 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
   }
   const bool small = c.w.slab_bytes > 0 && !vt_gemm_fast_eligible(p) && p.M <= 512 && p.K >= 512 && (p.K % 64) == 0 && (p.N % 4) == 0 && !p.hn_w0 &&
                      !p.hn_w1 && p.groups == 1 && p.taps == 0 && S >= 2 && (size_t)S * p.M * p.N * 4 <= c.w.slab_bytes;
-  if (!small) return vt_wrap(vt_gemm_launch(p, c.s), what);
+  if (!small) {
+    if (c.fuse_norm && pw_fuse && next_norm && xn_done && p.residual == p.C && p.c_dtype == VT_F32 && p.N == c.h->d.hidden && p.act == VT_ACT_NONE && p.ldc == p.N) {
+      p.xn_out = c.ws + c.w.xn; p.xn_ld = p.N; p.xn_gain = next_norm; p.xn_part = (float*)(c.ws + c.w.rs_part);
+      *xn_done = true;
+      c.rs_pending = true;
+    }
+    return vt_wrap(vt_gemm_launch(p, c.s), what);
+  }
   VtGemmParams q = p;
   q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
   q.bias = nullptr; q.act = VT_ACT_NONE; q.colscale = nullptr; q.residual = nullptr;
@@ -354,12 +364,33 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
   return attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att);
 }
 
+// the Linear about to run reads c.w.xn: if that is the un-normalised x * gain of a fused RMSNorm hand-off, it applies the rows' rstd itself
+void take_rstd(RCtx& c, VtGemmParams& p) {
+  if (!c.rs_pending) return;
+  c.rs_pending = false;
+  p.rs_part = (const float*)(c.ws + c.w.rs_part); p.rs_n = 2 * (c.h->d.hidden / 128); p.rs_inv_k = 1.0f / (float)c.h->d.hidden; p.rs_eps = 1e-6f;
+}
+
 // blocks + final layer on the fp32 stream x [B*(horizon+3)][D]; writes out_tok [B*(horizon+3)][out_dim] (adt)
 int run_blocks(RCtx& c, const uint8_t* lang_mask) {
   const vt_rdt_desc& d = c.h->d;
   const int D = d.hidden, N = d.horizon + 3, M = c.B * N, a = c.a;
   float* x = (float*)(c.ws + c.w.x);
   bool xn_ready = false;              // c.w.xn already holds the next norm of x (fused into the previous residual Linear's slab reduction)
+  // RMSNorm hand-off (VtGemmParams::xn_out / rs_part): when every Linear of a block runs on the weights-in-registers tile (batch 32: M = 2144) the three
+  // norm launches of a block disappear — the residual Linear writes x * gain + sums of squares, the next Linear scales its rows by rstd.
+  // Mean-square form only (the variance form of timm <= 1.0.8 needs the row mean as well); VLATOUCH_RDT_FUSE_NORM=0 for A/B.
+  {
+    static const bool on = [] { const char* e = getenv("VLATOUCH_RDT_FUSE_NORM"); return !e || atoi(e) != 0; }();
+    const Blk& b0 = c.h->blk[0];
+    VtGemmParams pr = lin(c.ws + c.w.att, d.adt, D, b0.proj_w, d.cdt, D, b0.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b0.proj_wp);
+    pr.residual = x; pr.ldr = D;
+    VtGemmParams c1 = lin(c.ws + c.w.xn, d.adt, D, b0.qkv_w, d.cdt, D, b0.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE, b0.qkv_wp);
+    VtGemmParams c2 = lin(c.ws + c.w.xn, d.adt, D, b0.cq_w, d.cdt, D, b0.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE, b0.cq_wp);
+    c.fuse_norm = on && d.rms_mode == VT_NORM_RMS_MEANSQ && c.w.slab_bytes == 0 && D % 128 == 0 && 2 * (D / 128) <= 32 && vt_gemm_fast_eligible(pr) &&
+                  vt_gemm_pw_eligible(pr) && vt_gemm_fast_eligible(c1) && vt_gemm_pw_eligible(c1) && vt_gemm_fast_eligible(c2) && vt_gemm_pw_eligible(c2);
+    c.rs_pending = false;
+  }
   for (int l = 0; l < d.depth; ++l) {
     const Blk& b = c.h->blk[l];
     const float* norm_after = l + 1 < d.depth ? c.h->blk[l + 1].norm1 : c.h->normf;     // the norm that follows this block's fc2
@@ -367,6 +398,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE, b.qkv_wp);
+      take_rstd(c, p);
       bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
       bool folded = false;
       CK(rgemm(c, p, "rdt qkv", fused ? nullptr : b.qn, D, b.kn, 2 * D, &folded));
@@ -383,6 +415,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE, b.cq_wp);
+      take_rstd(c, p);
       bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       bool folded = false;
       CK(rgemm(c, p, "rdt cross q", fused ? nullptr : b.cqn, D, nullptr, D, &folded));
@@ -396,10 +429,11 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, b.fc1_wp);
+      take_rstd(c, p);
       CK(rgemm(c, p, "rdt fc1")); }
     { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.fc2_wp);
       p.residual = x; p.ldr = D;
-      CK(rgemm(c, p, "rdt fc2", nullptr, 0, nullptr, 0, nullptr, norm_after, &xn_ready)); }
+      CK(rgemm(c, p, "rdt fc2", nullptr, 0, nullptr, 0, nullptr, norm_after, &xn_ready, l + 1 < d.depth)); }   // the final layer's fc1 is not a consumer of the hand-off
   }
   if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
   { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, c.h->ffc1_wp);

@@ -43,6 +43,9 @@ class GemmParams(C.Structure):
         ("cmap", C.c_int), ("cmap_T", C.c_int),
         ("Wp", C.c_void_p),
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("sk_cnt", C.c_void_p), ("sk_cnt_n", C.c_int),
+        # fused RMSNorm hand-off between two Linears (vt_gemm.h): producer side / consumer side
+        ("xn_out", C.c_void_p), ("xn_ld", C.c_long), ("xn_gain", C.c_void_p), ("xn_part", C.c_void_p),
+        ("rs_part", C.c_void_p), ("rs_n", C.c_int), ("rs_inv_k", C.c_float), ("rs_eps", C.c_float),
     ]
 
 

@@ -18,10 +18,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          colscale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None, splitk: int = 1,
          headnorm=None, cmap=None, wp: Optional[torch.Tensor] = None, sk_ws: Optional[torch.Tensor] = None,
-         sk_cnt: Optional[torch.Tensor] = None) -> torch.Tensor:
+         sk_cnt: Optional[torch.Tensor] = None, xn=None, rs=None) -> torch.Tensor:
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
-    cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout."""
+    cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout.
+    RMSNorm hand-off between two Linears on the weights-in-registers tile (csrc/vt_gemm.h): xn = (xn_out [M, N] 16-bit, gain [N] fp32, part [M, 2N/128] fp32) on the
+    residual Linear (fp32 out), rs = (part, eps) on the Linear that reads xn_out as `a`."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
@@ -53,6 +55,14 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if sk_ws is not None and sk_cnt is not None:      # split-K scratch of the small-M tile: fp32 slab area + zeroed int32 ticket counters
         assert sk_cnt.dtype == torch.int32
         p.sk_ws, p.sk_ws_bytes, p.sk_cnt, p.sk_cnt_n = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size(), sk_cnt.data_ptr(), sk_cnt.numel()
+    if xn is not None:
+        xo, gain, part = xn
+        assert xo.shape == (M, N) and xo.dtype == a.dtype and gain.dtype == torch.float32 and part.dtype == torch.float32 and part.shape == (M, 2 * N // 128)
+        p.xn_out, p.xn_ld, p.xn_gain, p.xn_part = xo.data_ptr(), xo.stride(0), gain.data_ptr(), part.data_ptr()
+    if rs is not None:
+        part, eps = rs
+        assert part.dtype == torch.float32 and part.shape[0] == M and part.is_contiguous()
+        p.rs_part, p.rs_n, p.rs_inv_k, p.rs_eps = part.data_ptr(), part.shape[1], 1.0 / K, eps
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
     return out
 
