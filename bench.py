@@ -443,7 +443,8 @@ def main():
                    "epilogue on registers inside the k-loop: fused condition K|V projections of RDT, image / language adaptors, DINOv2 qkv / fc1 / out-projection / fc2; "
                    "gemm_pp256d = the same tile, one launch block per tile, for the epilogue kinds the persistent kernel does not have)", "gemm_pp256")
     r_gl = roof(3, "gemm_pw_kernel (160x128x64 tile, frozen fragment-packed weights streamed global -> VGPR, activations through an LDS-DMA ring; with the few "
-                   "gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows, incl. the fused qkv projection)", "gemm_pw")
+                   "gemm_glds_kernel launches: the per-denoise-step Linears of RDT, M = batch x 67 rows, incl. the fused qkv projection; the RMSNorm between a "
+                   "residual Linear and the next Linear rides on their epilogues: x * gain + sums of squares out of the first, a row scale in the second)", "gemm_pw")
     r_at = None
     if prof.get(4, (0, 0, 0, 0))[3] > 0 and prof[4][0] > 0:
         ms_, fl_, by_, n_ = prof[4]
@@ -462,6 +463,7 @@ def main():
             r_at["softmax"] = "fixed" if n_fixed == len(sb) else ("online" if n_fixed == 0 else f"fixed in {n_fixed} of {len(sb)} blocks")
             r_at["score_bound_max"] = round(max(sb), 2) if sb else None
             r_at["rms_mode"] = rdt.rms_mode
+        r_at["tile_dma_cache_policy"] = "default" if os.environ.get("VLATOUCH_KVT_NT", "1") == "0" else "nt"
     r_uc = None
     if prof.get(6, (0, 0, 0, 0))[3] > 0 and prof[6][0] > 0:
         ms_, fl_, by_, n_ = prof[6]

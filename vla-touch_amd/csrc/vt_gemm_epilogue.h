@@ -10,6 +10,36 @@
 #include "vt_gemm.h"
 #include "vt_kernels.h"
 
+// global stores of the row-segment epilogue.  VT_EPI_ST_POLICY (set by a translation unit before including this header; A/B only): 1 = nt, 2 = sc0 sc1
+// (write-through): a short kernel that stores its whole output in its last microsecond leaves it dirty in L2 for the kernel boundary to write back
+#ifndef VT_EPI_ST_POLICY
+#define VT_EPI_ST_POLICY 0
+#endif
+__device__ __forceinline__ void vt_epi_st128(void* ptr, const float4 v) {
+#if VT_EPI_ST_POLICY == 1
+  typedef __attribute__((ext_vector_type(4))) float f4v;
+  __builtin_nontemporal_store((f4v){v.x, v.y, v.z, v.w}, reinterpret_cast<f4v*>(ptr));
+#elif VT_EPI_ST_POLICY == 2
+  typedef __attribute__((ext_vector_type(4))) float f4v;
+  const f4v t = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(t) : "memory");
+#else
+  *reinterpret_cast<float4*>(ptr) = v;
+#endif
+}
+__device__ __forceinline__ void vt_epi_st64(void* ptr, const uint2 v) {
+#if VT_EPI_ST_POLICY == 1
+  typedef __attribute__((ext_vector_type(2))) unsigned u2v;
+  __builtin_nontemporal_store((u2v){v.x, v.y}, reinterpret_cast<u2v*>(ptr));
+#elif VT_EPI_ST_POLICY == 2
+  typedef __attribute__((ext_vector_type(2))) unsigned u2v;
+  const u2v t = {v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(t) : "memory");
+#else
+  *reinterpret_cast<uint2*>(ptr) = v;
+#endif
+}
+
 constexpr int EP_LD = 68;                      // floats per row of the epilogue patch (64 + 4 pad, keeps 16-B alignment)
 constexpr int EPT_LD = 36;                     // transposed patch (cmap 2): 64 d-rows x 32 keys + 4 pad
 constexpr int EP_BYTES = 64 * EPT_LD * 4;      // per-wave patch: max(32 x EP_LD, 64 x EPT_LD) floats
@@ -47,7 +77,7 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
   } else if constexpr (sizeof(TC) == 4) {
     if (rpre) { o[0] += rpre->x; o[1] += rpre->y; o[2] += rpre->z; o[3] += rpre->w; }
     else if (Rg) { const float4 rv = *reinterpret_cast<const float4*>(Rg + (long)m * p.ldr + n); o[0] += rv.x; o[1] += rv.y; o[2] += rv.z; o[3] += rv.w; }
-    *reinterpret_cast<float4*>(Cg + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+    vt_epi_st128(Cg + (long)m * p.ldc + n, make_float4(o[0], o[1], o[2], o[3]));
   } else {
     if (Rg) {
       TC rv[4];
@@ -58,7 +88,7 @@ __device__ __forceinline__ void vt_epi_segment(const VtGemmParams& p, float4 x, 
     TC ov[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) ov[r] = Elem<TC>::from_f(o[r]);
-    *reinterpret_cast<uint2*>(Cg + (long)m * p.ldc + n) = *reinterpret_cast<const uint2*>(ov);
+    vt_epi_st64(Cg + (long)m * p.ldc + n, *reinterpret_cast<const uint2*>(ov));
   }
 }
 

@@ -23,6 +23,9 @@
 //     read back as whole row segments by vt_epi_segment (bias / per-head RMSNorm / activation / column scale / residual), the same
 //     arithmetic in the same order as vt_gemm_epilogue.h.
 #include <stdlib.h>
+#ifdef VLATOUCH_PW_ST
+#define VT_EPI_ST_POLICY VLATOUCH_PW_ST
+#endif
 #include "vt_common.h"
 #include "vt_gemm.h"
 #include "vt_gemm_epilogue.h"
@@ -291,9 +294,9 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
         const bool ok = m < p.M && col_ok;
         const float q = row16_sum(ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f);
         if (ok) {
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n) = make_float4(o[0], o[1], o[2], o[3]);
+          vt_epi_st128(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n, make_float4(o[0], o[1], o[2], o[3]));
           T16 ov[4] = {Elem<T16>::from_f(o[0] * g4.x), Elem<T16>::from_f(o[1] * g4.y), Elem<T16>::from_f(o[2] * g4.z), Elem<T16>::from_f(o[3] * g4.w)};
-          *reinterpret_cast<uint2*>(Xn + (long)m * p.xn_ld + n) = *reinterpret_cast<const uint2*>(ov);
+          vt_epi_st64(Xn + (long)m * p.xn_ld + n, *reinterpret_cast<const uint2*>(ov));
         }
         if (c4 == 0 && m < p.M) p.xn_part[(long)m * pn + pcol] = q;
       }
