@@ -11,6 +11,8 @@ P
 run full_n1
 run full_streams2_n1 --streams 2 --no-cpu-baseline
 run full_streams1_n1 --streams 1 --no-cpu-baseline
+run full_streams4_n1 --streams 4 --no-cpu-baseline
+run full_rmsvar_n1 --rms-mode var --no-cpu-baseline
 run pi_refine_n1 --workload pi_refine --no-cpu-baseline
 run pi_refine_streams1_n1 --workload pi_refine --no-cpu-baseline --streams 1
 run dino_mlp_n1 --workload dino_mlp --no-cpu-baseline
