@@ -29,3 +29,4 @@ def run(name, B, N, H, hd, hd_real, dt):
 
 run("siglip so400m (6 x 32 imgs)", 192, 729, 16, 80, 72, torch.float16)
 run("dinov2-b (2 x 32 imgs)", 64, 257, 12, 64, 64, torch.float16)
+run("rdt self-attention (B = 32)", 32, 67, 32, 64, 64, torch.bfloat16)
