@@ -241,6 +241,7 @@ template <> __device__ __forceinline__ void mma16_k16<half_t>(float4_t& acc, con
 
 #ifdef VLATOUCH_BENCH_BUILD      // timing-only ablations of attn16_kernel (tools/attn_abl.sh; garbage results): 1 = no softmax arithmetic, 2 = no P V, 4 = no Q K^T, 8 = no K / V staging after the first tiles
 __device__ int d_attn_abl = 0;
+__device__ long long* d_attn_tbuf = nullptr;   // optional phase time stamps of attn16u_kernel (tools/attn_phases.py): 4 x s_memrealtime per block
 #define VT_ATTN_ABL(bit) (d_attn_abl & (bit))
 #else
 #define VT_ATTN_ABL(bit) 0
@@ -449,6 +450,10 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
 // are (uniform tile base, SALU) + (per-lane piece offset, computed once) except in the last, clamped tile, and the first two stages are issued
 // BEFORE the Q fragments are loaded so that a block pays one memory round trip before its first MFMA, not two.
 template <int I> struct IC { static constexpr int value = I; };
+// 16-byte-chunk swizzle of the V tile's main image (attn16u_kernel): the Vt fragment read (ds_read_b64_tr_b16) takes 32 bytes = a PAIR of chunks per key, and the
+// 32 lanes of one LDS pass cover 8 keys — with the K tile's swizzle ((row >> 1) & 7: pairs only swap inside their 32-byte window) keys k and k + 2 hit the same banks
+// (PMC: 30 % of this kernel's LDS cycles were bank conflicts); moving whole pairs by (row >> 1) & 3 gives the 8 keys 8 distinct 32-byte windows of the 256-byte bank row.
+__device__ __forceinline__ int vswz(const int row) { return ((row >> 1) & 3) << 1; }
 
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
@@ -478,6 +483,11 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
   const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
   const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
   const int ntiles = (p.Nk + KT - 1) / KT;
+#ifdef VLATOUCH_BENCH_BUILD
+  const int lin_blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  long long* tb = (d_attn_tbuf && lin_blk < 4096 && tid == 0) ? d_attn_tbuf + (long)lin_blk * 4 : nullptr;
+  if (tb) tb[0] = wall_clock64();
+#endif
 
   // DMA plan (as attn16_kernel): the PIECES 1-KiB pieces of a stage are dealt round-robin over the waves.  poff[n] = this lane's element offset
   // inside the K (or V) rows of a tile for the wave's n-th piece.
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
     const unsigned rs = (unsigned)(isv ? p.v_rs : p.k_rs);
     if (TP == 0 || j < 8) {
       const int r = j * 8 + (lane >> 3);
-      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 8);
+      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ (isv ? vswz(r) : (r >> 1) & 7)) * 8);
     } else {
       const int r = (j - 8) * (64 / CPR) + lane / CPR;
       poff[n] = (unsigned)r * rs + 64u + (unsigned)((lane % CPR) * 8);
@@ -521,7 +531,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
         const long rs = isv ? p.v_rs : p.k_rs;
         if (TP == 0 || j < 8) {
           const int r = j * 8 + (lane >> 3);
-          const int c = (lane & 7) ^ ((r >> 1) & 7);
+          const int c = (lane & 7) ^ (isv ? vswz(r) : (r >> 1) & 7);
           __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
         } else {
           const int r = (j - 8) * (64 / CPR) + lane / CPR;
@@ -555,6 +565,9 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[ks].v));
   asm volatile("" : "+v"(q16));
+#ifdef VLATOUCH_BENCH_BUILD
+  if (tb) tb[1] = wall_clock64();
+#endif
 
   // per-lane LDS offsets inside a tile (see attn16_kernel for the fragment conventions)
   //   K fragment (key row kt*16 + l15, 16-byte chunk ks*4 + g, swizzled by (row >> 1) & 7 = (l15 >> 1) & 7):  kt*2048 + koff[ks]
@@ -566,7 +579,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
   const unsigned ktail = (unsigned)(MAINB + l15 * TW + g * 16);          // + kt*16*TW + (ks-2)*64; the 16-deep tail step reads ... + g*8 instead
   const unsigned ktail16 = (unsigned)(MAINB + l15 * TW + (NKS - 2) * 64 + g * 8);
   const int vkey = g * 4 + (l15 >> 2);
-  const int vsw = ((vkey >> 1) & 7) ^ ((l15 & 3) >> 1);
+  const int vsw = vswz(vkey) ^ ((l15 & 3) >> 1);
   unsigned voff[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) voff[dt] = (unsigned)(vkey * 128 + (((dt * 2) ^ vsw) * 16) + (l15 & 1) * 8);
@@ -678,6 +691,9 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
     body(IC<2>{}, tile + 2);
   }
 
+#ifdef VLATOUCH_BENCH_BUILD
+  if (tb) { asm volatile("" : "+v"(o[0])); tb[2] = wall_clock64(); }
+#endif
   float l = l_run;
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
@@ -690,9 +706,18 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
       *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = *reinterpret_cast<const uint2*>(ov);
     }
   }
+#ifdef VLATOUCH_BENCH_BUILD
+  if (tb) tb[3] = wall_clock64();
+#endif
 }
 
 }  // namespace
+
+#ifdef VLATOUCH_BENCH_BUILD
+extern "C" int vt_attn_set_timing(long long* buf) {      // bench build only: device buffer of 4096 x 4 stamps (null = off)
+  return hipMemcpyToSymbol(HIP_SYMBOL(d_attn_tbuf), &buf, sizeof(buf)) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
+}
+#endif
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
