@@ -450,10 +450,6 @@ __global__ __launch_bounds__(512) void attn16_kernel(const VtAttnParams p) {
 // are (uniform tile base, SALU) + (per-lane piece offset, computed once) except in the last, clamped tile, and the first two stages are issued
 // BEFORE the Q fragments are loaded so that a block pays one memory round trip before its first MFMA, not two.
 template <int I> struct IC { static constexpr int value = I; };
-// 16-byte-chunk swizzle of the V tile's main image (attn16u_kernel): the Vt fragment read (ds_read_b64_tr_b16) takes 32 bytes = a PAIR of chunks per key, and the
-// 32 lanes of one LDS pass cover 8 keys — with the K tile's swizzle ((row >> 1) & 7: pairs only swap inside their 32-byte window) keys k and k + 2 hit the same banks
-// (PMC: 30 % of this kernel's LDS cycles were bank conflicts); moving whole pairs by (row >> 1) & 3 gives the 8 keys 8 distinct 32-byte windows of the 256-byte bank row.
-__device__ __forceinline__ int vswz(const int row) { return ((row >> 1) & 3) << 1; }
 
 template <typename T, int HD>
 __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
@@ -501,7 +497,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
     const unsigned rs = (unsigned)(isv ? p.v_rs : p.k_rs);
     if (TP == 0 || j < 8) {
       const int r = j * 8 + (lane >> 3);
-      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ (isv ? vswz(r) : (r >> 1) & 7)) * 8);
+      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 8);
     } else {
       const int r = (j - 8) * (64 / CPR) + lane / CPR;
       poff[n] = (unsigned)r * rs + 64u + (unsigned)((lane % CPR) * 8);
@@ -531,7 +527,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
         const long rs = isv ? p.v_rs : p.k_rs;
         if (TP == 0 || j < 8) {
           const int r = j * 8 + (lane >> 3);
-          const int c = (lane & 7) ^ (isv ? vswz(r) : (r >> 1) & 7);
+          const int c = (lane & 7) ^ ((r >> 1) & 7);
           __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
         } else {
           const int r = (j - 8) * (64 / CPR) + lane / CPR;
@@ -579,7 +575,7 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
   const unsigned ktail = (unsigned)(MAINB + l15 * TW + g * 16);          // + kt*16*TW + (ks-2)*64; the 16-deep tail step reads ... + g*8 instead
   const unsigned ktail16 = (unsigned)(MAINB + l15 * TW + (NKS - 2) * 64 + g * 8);
   const int vkey = g * 4 + (l15 >> 2);
-  const int vsw = vswz(vkey) ^ ((l15 & 3) >> 1);
+  const int vsw = ((vkey >> 1) & 7) ^ ((l15 & 3) >> 1);
   unsigned voff[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) voff[dt] = (unsigned)(vkey * 128 + (((dt * 2) ^ vsw) * 16) + (l15 & 1) * 8);
