@@ -501,9 +501,33 @@ __global__ void bcast_row_kernel(const float* __restrict__ vec, float* __restric
 // ------------------------------------------------------------------ image statistics (max, sum) -> branch flags
 template <typename TI>
 __global__ __launch_bounds__(256) void imgstat_partial_kernel(const TI* __restrict__ img, long n, float* __restrict__ part) {
+  // 16 bytes per lane and four independent loads in flight (a grid-stride loop of 4-byte loads was 73 dependent round trips: 31 us for 19 MB)
+  constexpr int V = 16 / sizeof(TI);                       // elements per 16-byte vector
   float mx = -3.4e38f, sm = 0.f;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const float v = (float)img[i];
+  const long nvec = ((reinterpret_cast<size_t>(img) & 15) == 0) ? n / V : 0;
+  const long stride = (long)gridDim.x * 256;
+  auto take = [&](const uint4 q) {
+    if constexpr (sizeof(TI) == 4) {
+      const float* f = reinterpret_cast<const float*>(&q);
+      mx = fmaxf(fmaxf(mx, fmaxf(f[0], f[1])), fmaxf(f[2], f[3]));
+      sm += (f[0] + f[1]) + (f[2] + f[3]);
+    } else {
+      const uint8_t* u = reinterpret_cast<const uint8_t*>(&q);
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) { const float v = (float)u[k]; mx = fmaxf(mx, v); t += v; }
+      sm += t;
+    }
+  };
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const uint4* v4 = reinterpret_cast<const uint4*>(img);
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    const uint4 q0 = v4[i], q1 = v4[i + stride], q2 = v4[i + 2 * stride], q3 = v4[i + 3 * stride];
+    take(q0); take(q1); take(q2); take(q3);
+  }
+  for (; i < nvec; i += stride) take(v4[i]);
+  for (long e = nvec * V + (long)blockIdx.x * 256 + threadIdx.x; e < n; e += stride) {      // unaligned base or a tail that is not a whole vector
+    const float v = (float)img[e];
     mx = fmaxf(mx, v);
     sm += v;
   }
@@ -517,12 +541,21 @@ __global__ __launch_bounds__(256) void imgstat_partial_kernel(const TI* __restri
     part[2 * blockIdx.x + 1] = (ssm[0] + ssm[1]) + (ssm[2] + ssm[3]);
   }
 }
-// flags[0] = pixel scale (1 or 1/255), flags[1] = 1.0 if ImageNet normalisation applies (visual_encoder.py:78,100)
-__global__ void imgstat_final_kernel(const float* __restrict__ part, int nparts, long n, float pre_scale, int norm_mode, float* __restrict__ flags) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// flags[0] = pixel scale (1 or 1/255), flags[1] = 1.0 if ImageNet normalisation applies (visual_encoder.py:78,100).  One wave: lane l folds partials l, l + 64, ...
+// (a single lane walking all of them was 19 us)
+__global__ __launch_bounds__(64) void imgstat_final_kernel(const float* __restrict__ part, int nparts, long n, float pre_scale, int norm_mode, float* __restrict__ flags) {
+  if (blockIdx.x != 0) return;
   float mx = -3.4e38f;
   double sm = 0.0;
-  for (int i = 0; i < nparts; ++i) { mx = fmaxf(mx, part[2 * i]); sm += (double)part[2 * i + 1]; }
+  for (int i = threadIdx.x; i < nparts; i += 64) { mx = fmaxf(mx, part[2 * i]); sm += (double)part[2 * i + 1]; }
+  mx = wave_max(mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const long long bits = __builtin_bit_cast(long long, sm);
+    const int lo = __shfl_xor((int)(bits & 0xffffffffll), o, 64), hi = __shfl_xor((int)(bits >> 32), o, 64);
+    sm += __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+  }
+  if (threadIdx.x != 0) return;
   mx *= pre_scale;
   float scale = pre_scale;
   if (mx > 1.0f) scale = pre_scale / 255.0f;
@@ -544,6 +577,21 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TI* __restrict__ im
   const float mean[3] = {0.485f, 0.456f, 0.406f}, istd[3] = {1.f / 0.229f, 1.f / 0.224f, 1.f / 0.225f};
   const int W14 = grid_ * 14;   // used width (res may exceed grid*14; HF conv drops the remainder)
   const int total = 3 * 14 * W14;
+  if (!nhwc && sizeof(TI) == 4 && sizeof(TO) == 2 && (res & 1) == 0 && (kpad & 1) == 0 && (reinterpret_cast<size_t>(img) & 7) == 0) {
+    // planar fp32 frames -> 16-bit patches, two pixels per lane: x and x + 1 (x even) sit in the same patch (14 is even), so one 8-byte load and one 4-byte
+    // store replace two 4-byte loads and two 2-byte stores (the one-pixel loop below: 29 us per 32 frames of 224 x 224)
+    const int half = total >> 1, Wh = W14 >> 1;
+    for (int e = threadIdx.x; e < half; e += 256) {
+      const int c = e / (14 * Wh), r = e - c * 14 * Wh, i = r / Wh, xcol = (r - i * Wh) * 2;
+      const int yrow = py * 14 + i;
+      const float2 p2 = *reinterpret_cast<const float2*>(reinterpret_cast<const float*>(img) + (((long)b * 3 + c) * res + yrow) * res + xcol);
+      float v0 = p2.x * scale, v1 = p2.y * scale;
+      if (norm) { v0 = (v0 - mean[c]) * istd[c]; v1 = (v1 - mean[c]) * istd[c]; }
+      const int px = xcol / 14, j = xcol - px * 14;
+      TO o2[2] = {Elem<TO>::from_f(v0), Elem<TO>::from_f(v1)};
+      *reinterpret_cast<uint32_t*>(out + ((long)(b * grid_ + py) * grid_ + px) * kpad + c * 196 + i * 14 + j) = *reinterpret_cast<const uint32_t*>(o2);
+    }
+  } else
   for (int e = threadIdx.x; e < total; e += 256) {
     int c, i, xcol;
     if (nhwc) { i = e / (W14 * 3); const int r = e - i * W14 * 3; xcol = r / 3; c = r - xcol * 3; }
@@ -706,7 +754,7 @@ int vt_k_bcast_row(const float* vec, float* out, long row_stride, int B, int D, 
 }
 
 int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s) {
-  const int nb = 256;
+  const int nb = 256;                  // the callers' partials buffers hold 256 x 2 floats per camera
   if (is_u8) hipLaunchKernelGGL((imgstat_partial_kernel<uint8_t>), dim3(nb), dim3(256), 0, s, (const uint8_t*)img, n, part);
   else hipLaunchKernelGGL((imgstat_partial_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)img, n, part);
   hipLaunchKernelGGL(imgstat_final_kernel, dim3(1), dim3(64), 0, s, part, nb, n, pre_scale, norm_mode, flags);
