@@ -167,6 +167,11 @@ int vt_dino_create(const vt_dino_desc* desc, const void* const* weights, int n_w
 void vt_dino_destroy(vt_dino_t h);
 int vt_dino_num_weights(const vt_dino_desc* desc);
 size_t vt_dino_workspace_bytes(vt_dino_t h, int B_total, int res);
+/* Optional fragment-packed second copies of the fc1 weights (vt_pack_w32 layout; 16-bit modes, GELU FFN): the caller allocates vt_dino_packed_bytes(h) bytes
+ * (0 = not applicable) and keeps them resident; vt_dino_set_packed enqueues the packing kernels.  With them the rows a 256-row tiling of the token matrix leaves
+ * over, and the CLS-only last block, run fc1 on the small-M packed-weight tile.  Replaces nothing in the reference (a layout of its nn.Linear weights). */
+size_t vt_dino_packed_bytes(vt_dino_t h);
+int vt_dino_set_packed(vt_dino_t h, void* buf, vt_stream_t stream);
 /* imgs[ncams] device pointers; is_u8: uint8 pixels else fp32; nhwc: [B,H,W,3] else [B,3,H,W];
  * pre_scale: 1/255 when the caller passed a numpy array (visual_encoder.py:66) else 1;
  * norm_mode: 0 auto (reference behaviour), 1 force ImageNet-normalise, 2 never;

@@ -34,6 +34,7 @@ static VtGemmParams lin(const void* A, int adt, long lda, const void* W, int cdt
 struct DinoLayer {
   const float *ln1_w, *ln1_b, *qkv_b, *proj_b, *ls1, *ln2_w, *ln2_b, *fc1_b, *fc2_b, *ls2;
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+  const void* fc1_wp;      // optional fragment-packed copy of fc1 (vt_dino_set_packed): the <= 64-row remainder of fc1's exact row split runs on the small-M packed-weight tile
 };
 struct vt_dino_s {
   vt_dino_desc d;
@@ -69,6 +70,33 @@ int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_din
   return VT_OK;
 }
 void vt_dino_destroy(vt_dino_t h) { delete h; }
+
+// Optional fragment-packed second copies of the fc1 weights (vt_pack_w32 layout; 16-bit, GELU FFN, hidden % 256 == 0, mlp % 64 == 0): with them the few rows a
+// 256-row tiling of B x N tokens leaves over (DINOv2-base, 64 images: 64 x 257 = 64 x 256 + 64) and the CLS-only last block take vt_gemm_pws.hip (5 us) instead of
+// the register-staged generic GEMM (18 us, 12 launches per forward).  The caller owns `buf` (vt_dino_packed_bytes(h) bytes, resident while the handle is used).
+static bool dino_pk_ok(const vt_dino_s* h) {
+  const int D = h->d.hidden, Dm = h->d.mlp_dim ? h->d.mlp_dim : 4 * D;
+  return h->d.cdt != VT_F32 && h->d.adt == h->d.cdt && h->d.act != VT_ACT_SWIGLU && D % 256 == 0 && Dm % 64 == 0;
+}
+size_t vt_dino_packed_bytes(vt_dino_t h) {
+  if (!h || !dino_pk_ok(h)) return 0;
+  const size_t D = h->d.hidden, Dm = h->d.mlp_dim ? h->d.mlp_dim : 4 * D;
+  return (size_t)h->d.layers * Dm * D * 2;
+}
+int vt_dino_set_packed(vt_dino_t h, void* buf, vt_stream_t stream) {
+  if (!h) return vt_fail(VT_ERR_ARG, "vt_dino_set_packed: null handle");
+  if (!vt_dino_packed_bytes(h)) return vt_fail(VT_ERR_UNSUPPORTED, "vt_dino_set_packed: this configuration has no packed weights");
+  if (!buf) return vt_fail(VT_ERR_ARG, "vt_dino_set_packed: null buffer");
+  const int D = h->d.hidden, Dm = h->d.mlp_dim ? h->d.mlp_dim : 4 * D;
+  char* o = (char*)buf;
+  for (int l = 0; l < h->d.layers; ++l) {
+    const int r = vt_pack_w32(h->L[l].fc1_w, D, o, Dm, D, stream);
+    if (r) return r;
+    h->L[l].fc1_wp = o;
+    o += (size_t)Dm * D * 2;
+  }
+  return VT_OK;
+}
 
 namespace {
 constexpr int DINO_SPLITK = 4, DINO_SPLIT_ROWS = 1100;
@@ -135,6 +163,8 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
   auto ffn = [&](const DinoLayer& L, int rows, long tok_stride) -> int {
     const int N1 = swiglu ? 2 * Dm : Dm;
     { VtGemmParams p = lin(ws + w.xn, d.adt, D, L.fc1_w, d.cdt, D, L.fc1_b, ws + w.h1, d.adt, N1, rows, N1, D, swiglu ? VT_ACT_NONE : act);
+      p.Wp = swiglu ? nullptr : L.fc1_wp;
+      if (p.Wp && vt_gemm_fast_eligible(p) && vt_gemm_pw_eligible(p)) p.Wp = nullptr;   // the 160 x 128 weights-in-registers tile is the RDT denoise loop's; ViT GEMMs stay on the persistent tile
       CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
     if (swiglu) CK(vt_wrap(vt_k_swiglu(ws + w.h1, d.adt, N1, rows, Dm, s), "dino swiglu gate"));
     { VtGemmParams p = lin(ws + w.h1, d.adt, N1, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tok_stride, rows, D, Dm, VT_ACT_NONE);

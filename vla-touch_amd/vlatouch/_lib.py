@@ -148,6 +148,8 @@ SIGNATURES = {
     "vt_dino_destroy": (None, [_P]),
     "vt_dino_num_weights": (_I, [_P]),
     "vt_dino_workspace_bytes": (_Z, [_P, _I, _I]),
+    "vt_dino_packed_bytes": (_Z, [_P]),
+    "vt_dino_set_packed": (_I, [_P, _P, _P]),
     "vt_dino_forward": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
     "vt_mlp": (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
     "vt_concat_obs": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P]),

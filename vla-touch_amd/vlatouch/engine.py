@@ -270,6 +270,13 @@ class DinoEngine:
         assert lib.vt_dino_num_weights(C.byref(desc)) == len(W)
         self._h = C.c_void_p()
         L.check(lib.vt_dino_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_dino_create")
+        # fragment-packed second copies of the fc1 weights (16-bit GELU models): the rows a 256-row tiling of the token matrix leaves over, and the CLS-only last
+        # block, run fc1 on the small-M packed-weight tile (csrc/vt_gemm_pws.hip)
+        nb = lib.vt_dino_packed_bytes(self._h)
+        if nb:
+            self._packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
+            L.check(lib.vt_dino_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_dino_set_packed")
+            torch.cuda.synchronize(self.device)
         self._ws = _Workspace(self.device)
         self._pos_cache: Dict[int, torch.Tensor] = {}
         self.last_flags: Optional[torch.Tensor] = None
