@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Mapping, Optional, Sequence
 
 import torch
@@ -272,7 +273,7 @@ class DinoEngine:
         L.check(lib.vt_dino_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_dino_create")
         # fragment-packed second copies of the fc1 weights (16-bit GELU models): the rows a 256-row tiling of the token matrix leaves over, and the CLS-only last
         # block, run fc1 on the small-M packed-weight tile (csrc/vt_gemm_pws.hip)
-        nb = lib.vt_dino_packed_bytes(self._h)
+        nb = lib.vt_dino_packed_bytes(self._h) if os.environ.get("VLATOUCH_DINO_PACKED", "1") != "0" else 0     # =0: A/B without the packed fc1 copy
         if nb:
             self._packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
             L.check(lib.vt_dino_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_dino_set_packed")
