@@ -45,6 +45,7 @@ def main():
         from vlatouch.dist import controller_weight_tensors
         for w in controller_weight_tensors(ctrl) + list(r.engine()._weights):
             w.mul_(0.5)
+        ctrl.image_encoder.engine.repack()     # derived copies (the DINOv2 engine's fragment-packed fc1) follow the corrupted weights: the broadcast must rebuild them
         torch.cuda.synchronize()
         wrong = ctrl.predict(*args(), noise=z[:, sl].contiguous())
         assert not torch.equal(wrong, before), "corrupting the weights must change the result"

@@ -94,6 +94,9 @@ def broadcast_controller_weights(ctrl, src: int = 0) -> int:
     net = ctrl.diffusion_model
     nets = ("v_net", "s_net") if net.sde_type == "vs" else ("b_net", "s_net")
     net._sampler_engine(nets, torch.device(ctrl.device)).repack()
+    rp = getattr(ctrl.image_encoder.engine, "repack", None)
+    if rp is not None:
+        rp()                                    # the DINOv2 engine's fragment-packed fc1 copy
     for k, v in ctrl.stats.items():
         broadcast_tensors([v], src)
     return n

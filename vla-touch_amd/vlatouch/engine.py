@@ -289,6 +289,12 @@ class DinoEngine:
         except Exception:
             pass
 
+    def repack(self) -> None:
+        """Rebuild the fragment-packed fc1 copy from `self._weights` (after they were overwritten in place, e.g. by the one-time broadcast of rank 0's
+        weights, vlatouch/dist.py)."""
+        if getattr(self, "_packed", None) is not None:
+            L.check(L.lib().vt_dino_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_dino_set_packed")
+
     def pos_patch(self, grid: int) -> torch.Tensor:
         """Position embeddings of the patch tokens for a grid x grid image: input-independent, so the bicubic
         resize of HF `interpolate_pos_encoding` (modeling_dinov2.py:57-95) is done once per resolution at load."""
