@@ -65,10 +65,15 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--cpu-batch", type=int, default=8, help="episodes in the CPU-baseline sample of the pi_I leg")
+    ap.add_argument("--force-dim", type=int, default=3,
+                    help="width of the tactile vector m_t fed to the observation MLP (reference default 3 = the marker tracker's force estimate, "
+                         "bridge_controller.py:25; BASELINE.json's synthetic workload names a 64-d tactile vector: --force-dim 64)")
+    ap.add_argument("--latency-steps", type=int, default=6,
+                    help="steps of the extra ONE-batch-at-a-time pass run after the timed region (reported as `latency_mode`; 0 = skip)")
     return ap.parse_args()
 
 
-def synth_inputs(B, T, res, seed, device):
+def synth_inputs(B, T, res, seed, device, force_dim=3):
     """frames 0.2+0.8*U(0,1) (batch mean ~0.6 -> the reference's normalise branch), state/force N(0,1),
     vla U(0,1), unit stats."""
     from vlatouch import synth
@@ -78,7 +83,7 @@ def synth_inputs(B, T, res, seed, device):
         cam1=mk((0.2 + 0.8 * g.random((B, 3, res, res), dtype=np.float32))),
         cam2=mk((0.2 + 0.8 * g.random((B, 3, res, res), dtype=np.float32))),
         state=mk(g.standard_normal((B, 10), dtype=np.float32)),
-        forces=mk(g.standard_normal((B, 3), dtype=np.float32)),
+        forces=mk(g.standard_normal((B, force_dim), dtype=np.float32)),
         vla=mk(g.uniform(0, 1, (B, T, 10)).astype(np.float32)),
     )
 
@@ -120,7 +125,11 @@ def main():
     torch.set_grad_enabled(False)
     dist = None
     bcast_bytes, bcast_s = 0, 0.0
-    if world > 1:
+    # a process group whenever the launcher set one up (torch.distributed.run exports WORLD_SIZE — also for `--gpus 1`, so that the RCCL path
+    # — communicator, weight broadcast, barrier, max-reduce of the timing — runs on one GPU exactly as it does on eight); plain
+    # `python bench.py` (N = 1) stays free of torch.distributed
+    use_dist = "WORLD_SIZE" in os.environ
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if share:
@@ -136,8 +145,8 @@ def main():
     t0 = time.time()
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):       # the mirrored reference classes print while they build ("init SI without model args"): stdout carries ONE JSON line
-        ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats())
-    if world > 1:
+        ctrl = synth.build_controller(DiffusionController, precision=args.precision, device=dev, size=args.dino, stats=synth.unit_stats(), force_dim=args.force_dim)
+    if use_dist:
         from vlatouch.dist import broadcast_controller_weights
         torch.cuda.synchronize(dev)
         tb = time.time()
@@ -146,10 +155,13 @@ def main():
         bcast_s += time.time() - tb
     setup_s = time.time() - t0
     B, T = args.batch, args.horizon
-    inp = synth_inputs(B, T, args.res, 1234 + rank, dev)
     # batches in flight by default: 3 for the RDT / pi_I workloads (round 4, measured on one box: full 410 -> 422 chunks/s, rdt 459 -> 464, pi_refine 4 277 -> 4 536,
     # lstm 6 952 -> 7 342; 4 in flight: 404), 2 for `robot` (137 vs 134 with 3), 1 for the rest
     n_streams = args.streams if args.streams > 0 else (3 if args.workload in ("full", "rdt", "pi_refine", "lstm") else (2 if args.workload == "robot" else 1))
+    # every batch in flight reads its OWN input set (frames, state, tactile vector; below: its own condition tokens): independent batches of a
+    # real pipeline share nothing but the weights, and the metric must not profit from cache reuse between slots
+    inps = [synth_inputs(B, T, args.res, 1234 + rank + 1000 * si, dev, args.force_dim) for si in range(n_streams)]
+    inp = inps[0]
     noise_bufs = [torch.empty(10, B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
     out_holders = [{} for _ in range(n_streams)]
     vla_bufs = [torch.empty(B, T, 10, dtype=torch.float32, device=dev) for _ in range(n_streams)]
@@ -172,7 +184,7 @@ def main():
                         max_lang_cond_len=1024, img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False)
         rdt.load_state_dict(synth.fill_state_dict_device(synth.rdt_runner_shapes(**RDT1B), dev, rdt_dtype, seed=7), assign=True)
         eng = rdt.engine()
-        if world > 1:
+        if use_dist:
             from vlatouch.dist import broadcast_tensors
             torch.cuda.synchronize(dev)
             tb = time.time()
@@ -184,8 +196,10 @@ def main():
         rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32).to(rdt_dtype)
         amask = torch.zeros(B, 1, 128, device=dev, dtype=rdt_dtype)
         amask[:, :, :10] = 1.0                                       # the 10 EEF dims of the unified action vector
-        rin = dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
-                   state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
+        mk_rin = lambda: dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
+                              state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
+        rins = [mk_rin() for _ in range(n_streams)]               # 322 MB of image tokens per slot
+        rin = rins[0]
     lstm = lstm_in = None
     dino_c = synth.DINOV2_CONFIGS[args.dino]
     dino_sd = synth.torch_state_dict(synth.dinov2_shapes(dino_c["hidden"], dino_c["layers"]), prefix=f"dinov2-{args.dino}.")
@@ -197,7 +211,8 @@ def main():
             getattr(lstm, name).load_state_dict(synth.torch_state_dict(shp, prefix=f"lstm_ctrl.{name}."))
         lstm.to(dev)
         lstm.stats = {k: v.to(dev) for k, v in synth.unit_stats().items()}
-        lstm_in = dict(forces=torch.randn(B, T, 3, device=dev))
+        lstm_ins = [dict(forces=torch.randn(B, T, 3, device=dev)) for _ in range(n_streams)]
+        lstm_in = lstm_ins[0]
     mk = mk_frames = None
     if args.workload == "marker":       # GelSight frames -> marker displacements + force estimate, a 256-frame stream per step
         from residual_controller.tactile.marker.marker_tracker import EnhancedMarkerTracker
@@ -215,13 +230,18 @@ def main():
         ssd = synth.fill_state_dict_device(synth.siglip_shapes(**c), dev, wdt, seed=9)
         sig = SiglipEngine({k: v.cpu() for k, v in ssd.items()}, heads=c["heads"], precision="fp16" if args.precision == "bf16" else "fp32", device=dev)
         del ssd
-        sig_px = (2.0 * torch.rand(6 * B, 3, 384, 384, device=dev) - 1.0)
+        sig_pxs = [(2.0 * torch.rand(6 * B, 3, 384, 384, device=dev) - 1.0) for _ in range(n_streams)]
+        sig_px = sig_pxs[0]
         if args.workload == "robot":
             tok_bufs = [torch.empty(6 * B, 729, 1152, dtype=rdt_dtype, device=dev) for _ in range(n_streams)]
     setup_s = time.time() - t0
 
     def step(slot=0):
         out_holder, noise_buf = out_holders[slot], noise_bufs[slot]
+        inp = inps[slot]
+        rin = rins[slot] if rdt is not None else None
+        lstm_in = lstm_ins[slot] if lstm is not None else None
+        sig_px = sig_pxs[slot] if sig is not None else None
         if args.workload == "lstm":
             obs = lstm.encode_observation(inp["state"], inp["cam1"], inp["cam2"])
             out_holder["out"] = lstm.predict_sequence(obs, inp["vla"], lstm_in["forces"])
@@ -326,6 +346,17 @@ def main():
         p50 = lat[len(lat) // 2]
         out_holder = out_holders[0]
 
+        # ---- latency mode inside the same run: ONE batch at a time (slot 0's graph back to back on its stream) — what a caller that waits for
+        #      each refined batch sees; same barrier + synchronize bracket, same max over ranks
+        lat_elapsed = None
+        if args.latency_steps > 0 and n_streams > 1:
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.latency_steps):
+                run(0)
+            barrier()
+            lat_elapsed = time.perf_counter() - t1
+
         # ---- roofline leg: one eager step with HIP events around every launch of the dominant GEMM kernel
         lib = L.lib()
         prof = {}
@@ -339,9 +370,11 @@ def main():
             prof[mode] = (ms.value, fl.value, by.value, n.value)
 
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        tt = torch.tensor([elapsed, lat_elapsed or 0.0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        elapsed = float(tt[0].item())
+        if lat_elapsed is not None:
+            lat_elapsed = float(tt[1].item())
     total_chunks = B * world * args.steps * (8 if args.workload == "marker" else 1)
     value = total_chunks / elapsed
 
@@ -371,11 +404,17 @@ def main():
         "metric": WL[0],
         "value": round(value, 2), "unit": "frames/s" if args.workload == "marker" else "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 4), "p50_step_latency_ms": round(p50, 4),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 (DINOv2 tower: IEEE fp16)" if args.precision == "bf16" else "fp32",
+        "dtypes": ({"rdt": "bf16 storage + bf16 MFMA, fp32 residual stream and accumulation", "dinov2": "IEEE fp16 storage + f16 MFMA, fp32 residual stream",
+                    "siglip": "IEEE fp16 storage + f16 MFMA", "obs_mlp": "fp32", "unet_sampler": "fp32 storage, split-bf16 (3 bf16 MFMAs per product)",
+                    "lstm_head": "fp32 storage, split-bf16"} if args.precision == "bf16" else {"all": "fp32 storage + fp32 MFMA"}),
+        "data": "synthetic",
         "config": {
             "workload": WL[1],
             "batch_per_gpu": B, "global_batch": B * world, "horizon": T, "parallelism": f"dp{world} (episodes sharded, no step collectives)",
-            "hipgraph": graph is not None, "batches_in_flight": n_streams,
+            "hipgraph": graph is not None, "batches_in_flight": n_streams, "inputs": "one synthetic input set per batch in flight (no sharing between slots)",
+            "tactile_vector_dim": args.force_dim,
             "ms_per_step_semantics": "wall time of the timed region / steps; with batches_in_flight > 1 consecutive steps (independent batches) "
                                      "overlap on separate HIP streams, so p50_step_latency_ms (enqueue -> completion of one batch) exceeds ms_per_step", "rdt_mode": "bf16 storage + bf16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32",
             "dino_mode": "IEEE fp16 storage + f16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32", "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
@@ -383,13 +422,21 @@ def main():
                        "not in the reference)", "setup_s": round(setup_s, 1),
         },
     }
+    # one batch at a time: chunks/s and ms per step with nothing else in flight (`--streams 1`); with one stream the timed region IS that mode
+    if lat_elapsed is not None:
+        res["latency_mode"] = {"chunks_per_s": round(B * world * args.latency_steps * (8 if args.workload == "marker" else 1) / lat_elapsed, 2),
+                               "ms_per_step": round(1000 * lat_elapsed / args.latency_steps, 4), "steps": args.latency_steps, "batches_in_flight": 1,
+                               "note": "same graphs, slot 0 replayed back to back after the timed region; `value` above is the throughput mode"}
+    elif n_streams == 1:
+        res["latency_mode"] = {"chunks_per_s": res["value"], "ms_per_step": res["ms_per_step"], "steps": args.steps, "batches_in_flight": 1,
+                               "note": "the timed region itself (one batch in flight)"}
     # end-to-end matrix-pipe fraction: SURVEY 8(d)'s algorithmic GFLOP per chunk (2 MAC, cached condition K/V, no recompute credit) x chunks / wall time
     gf_chunk = {"full": (1030.0 + 168.0 * args.rdt_steps + 57.0) + 99.3, "rdt": 1030.0 + 168.0 * args.rdt_steps + 57.0, "pi_refine": 99.3, "dino_mlp": 92.6}.get(args.workload)
     if gf_chunk is not None and args.dino == "base" and args.horizon == 16:
         tf = gf_chunk * total_chunks / elapsed / 1e3
         res["end_to_end_mfma"] = {"algorithmic_gflop_per_chunk": round(gf_chunk, 1), "achieved_tflops": round(tf, 1), "peak_tflops": PEAK_BF16_TFLOPS * world,
                                   "frac": round(tf / (PEAK_BF16_TFLOPS * world), 4), "note": "whole step incl. HBM- and launch-bound phases against the dense bf16 MFMA peak"}
-    if world > 1:
+    if dist is not None:
         res["config"]["weight_broadcast"] = {"bytes": int(bcast_bytes), "seconds": round(bcast_s, 3), "backend": dist.get_backend(),
                                              "note": "one-time, before the timed region; no collective inside the step loop"}
     # HBM-side traffic per launch comes from separate rocprofv3 --pmc passes (tools/pmc_summary.py); the committed summary of
@@ -501,7 +548,7 @@ def main():
         CB = min(B, args.cpu_batch)
         cpu = {k: v[:CB].cpu() for k, v in inp.items()}
         z = torch.randn(10, CB, T, 10)
-        sds = (dino_sd, synth.torch_state_dict(synth.state_encoder_shapes(2 * dino_c["hidden"] + 13), prefix="state_encoder."),
+        sds = (dino_sd, synth.torch_state_dict(synth.state_encoder_shapes(2 * dino_c["hidden"] + 10 + args.force_dim), prefix="state_encoder."),
                synth.torch_state_dict(synth.si_net_shapes(10, 256), prefix="si.", salt="ema"), synth.unit_stats())
         heads = 12 if args.dino == "base" else 6
         f = lambda: oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"], cpu["vla"], cpu["cam1"], cpu["cam2"], cpu["forces"], z)
@@ -523,8 +570,12 @@ def main():
             # the benchmarked configuration (B = 32 rows through the large-batch kernels; oracle = fp32 math on the bf16-rounded weights)
             gx = torch.Generator(device=dev).manual_seed(99)
             x_init = torch.randn(B, 64, 128, generator=gx, device=dev, dtype=torch.float32).to(rdt_dtype)
+            zc = torch.randn(10, B, T, 10)
             with torch.cuda.stream(stream):
                 gpu_chunk = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init)
+                # the CHAIN of the step, on the same inputs: fp32 hand-over of the chunk -> first T ticks x 10 EEF dims -> predict (all B episodes)
+                chunk32 = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init, return_fp32=True)
+                gpu_chain = ctrl.predict(inp["state"], _ops.slice_cast(chunk32, T, 10), inp["cam1"], inp["cam2"], inp["forces"], noise=zc.to(dev))
                 stream.synchronize()
             t1 = time.perf_counter()
             ref_chunk = orr.predict_action(sd_cpu, c1["lang"], c1["mask"], c1["img"], c1["state"], c1["amask"], c1["freq"], x_init[:1].float().cpu(),
@@ -533,16 +584,37 @@ def main():
             rdt_diff = float((gpu_chunk[0].float().cpu() - ref_chunk[0]).abs().max())
             rdt_scale = float(ref_chunk.abs().max())
             sample += f"; RDT-1B: 1 oracle predict_action on 1 episode ({args.rdt_steps} steps, fp32)"
+            # a_hat of episode 0 through the oracle's own chain: oracle chunk -> oracle predict (the quantity the 1e-2 tolerance is stated on)
+            ref_chain = oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"][:1], ref_chunk[:1, :T, :10], cpu["cam1"][:1], cpu["cam2"][:1],
+                                   cpu["forces"][:1], zc[:, :1])
+            chain_diff = float((gpu_chain[0].cpu() - ref_chain[0]).abs().max())
         try:
             cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
         except Exception:
             cpu_model = "unknown"
+        try:        # physical cores = distinct (socket, core id) pairs
+            phys, cur = set(), {}
+            for l in open("/proc/cpuinfo"):
+                if ":" in l:
+                    k_, v_ = (x.strip() for x in l.split(":", 1))
+                    cur[k_] = v_
+                elif cur:
+                    phys.add((cur.get("physical id"), cur.get("core id"))); cur = {}
+            n_phys = len(phys) or None
+        except Exception:
+            n_phys = None
         res["cpu_baseline"] = {"value": round(1.0 / (t_pi + t_rdt), 3), "unit": "chunks/s", "cores": cores, "cpu_model": cpu_model,
-                               "host_logical_cpus": os.cpu_count(), "kind": "port", "sample": sample,
+                               "host_logical_cpus": os.cpu_count(), "host_physical_cores": n_phys,
+                               "cores_note": f"{cores} torch intra-op threads of {n_phys} physical cores / {os.cpu_count()} logical CPUs (more threads stall in OpenMP spin barriers); "
+                                             "a bounded sample, not the same amount of work as a GPU step",
+                               "kind": "port", "sample": sample,
                                "pi_s_per_chunk": round(t_pi, 4), "rdt_s_per_chunk": round(t_rdt, 3),
                                "max_abs_diff_vs_gpu_pi": float((got - ref).abs().max())}
         if args.workload == "full":
-            res["cpu_baseline"].update({"max_abs_diff_vs_gpu_rdt": rdt_diff, "rdt_output_scale": rdt_scale,
+            res["cpu_baseline"].update({"max_abs_diff_vs_gpu_chain": chain_diff,
+                                        "chain_parity_note": "a_hat of episode 0: GPU RDT-1B bf16 chunk (B=%d) -> slice -> predict vs oracle chunk -> oracle predict, "
+                                                             "same start noise and SDE noise; north-star tolerance 1e-2 (flat)" % B,
+                                        "max_abs_diff_vs_gpu_rdt": rdt_diff, "rdt_output_scale": rdt_scale,
                                         "rdt_parity_note": "GPU batch row 0 (bf16, B=%d) vs oracle fp32 on the same bf16-rounded weights / inputs / start noise" % B})
     if rank == 0:
         print(json.dumps(res))

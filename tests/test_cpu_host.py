@@ -251,3 +251,27 @@ def test_fused_unet_plan_coverage_is_decided_per_shape_on_the_host():
     assert lib.vt_unet_fused_plan_bytes(narrow, 64, 8, 10) > 0      # tile choice bounded to 256 GroupNorm units per block
     fp32 = handle((256, 512, 512), cdt=0)
     assert lib.vt_unet_fused_plan_bytes(fp32, 4, 16, 10) == 0       # exact-fp32 mode has no fused path
+
+
+def test_interpolant_schedule_tables_match_the_oracle():
+    """The mirror's epsilon / gamma / gamma_der / gamma_inv are string-keyed table lookups (bridge_model.py:59-101 of the reference as data);
+    every key against the oracle's restatement (itself pinned to the reference through g2's trajectories), and unknown keys raise NotImplementedError."""
+    import pytest
+    from oracle import interpolant as oi
+    from residual_controller.bridge import bridge_model as bm
+    t = torch.linspace(0.001, 0.999, 97)
+    si = bm.StochasticInterpolants.__new__(bm.StochasticInterpolants)
+    si.gamma_inv_max = 200.0
+    assert set(bm._GAMMA_OF_T) == set(bm._GAMMA) and set(bm._EPSILON_OF_T) == set(bm._EPS)
+    for k in bm._EPS:
+        si.epsilon_type = k
+        assert torch.allclose(si.epsilon(t), oi.epsilon(t, k), rtol=0, atol=1e-6), k
+    for k in bm._GAMMA:
+        si.gamma_type = k
+        for name in ("gamma", "gamma_der", "gamma_inv"):
+            got, ref = getattr(si, name)(t), getattr(oi, name)(t, k)
+            assert torch.allclose(got, ref, rtol=1e-6, atol=1e-6), (k, name, float((got - ref).abs().max()))
+    si.gamma_type = si.epsilon_type = "nope"
+    for name in ("gamma", "gamma_der", "gamma_inv", "epsilon"):
+        with pytest.raises(NotImplementedError):
+            getattr(si, name)(t)

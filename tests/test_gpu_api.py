@@ -238,6 +238,41 @@ def test_predict_edge_shapes_vs_oracle(controllers, B, T, res, layout):
     assert err(got, ref.numpy()) < TOL["fp32"], err(got, ref.numpy())
 
 
+@pytest.mark.parametrize("B,size,force_dim", [(2, "small", 64), (32, "base", 64), (3, "small", 1), (4, "small", 17)])
+def test_predict_tactile_vector_widths_vs_oracle(B, size, force_dim):
+    """The tactile input m_t at other widths than the marker tracker's 3-d force estimate: `force_dim` is a constructor argument of the
+    reference (bridge_controller.py:25; obs_dim = 2*latent + state_dim + force_dim, :40-48; cat at :129-132) and BASELINE.json's synthetic
+    workload names a 64-d tactile vector.  B = 32 / DINOv2-base / 64-d is that workload's pi_I leg exactly; 1 and 17 make the concatenated
+    row end off every padding boundary of the observation MLP's first Linear.  Both precisions against the oracle run live."""
+    from oracle import controller as oc
+    from residual_controller.bridge_controller import DiffusionController
+    T = 16
+    g = np.random.default_rng(6400 + B + force_dim)
+    state = torch.from_numpy(g.standard_normal((B, 10)).astype(np.float32))
+    forces = torch.from_numpy(g.standard_normal((B, force_dim)).astype(np.float32))
+    vla = torch.from_numpy(g.uniform(0, 1, (B, T, 10)).astype(np.float32))
+    z = torch.from_numpy(g.standard_normal((10, B, T, 10)).astype(np.float32))
+    cam1 = torch.from_numpy((0.2 + 0.8 * g.random((B, 3, 224, 224))).astype(np.float32))
+    cam2 = torch.from_numpy((0.6 * g.random((B, 3, 224, 224))).astype(np.float32))
+    latent, heads = (384, 6) if size == "small" else (768, 12)
+    obs_dim = 2 * latent + 10 + force_dim
+    if B > 8:                                                                  # DINOv2-base on 64 frames: give the oracle the host's cores
+        torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    ref = oc.predict(cases.dino_sd(size), heads, cases.state_encoder_sd(obs_dim), cases.si_net_sd("ema"), cases.stats("nontrivial"),
+                     state, vla, cam1, cam2, forces, z)
+    for prec in ("fp32", "bf16"):
+        ctrl = cases.build_controller(DiffusionController, precision=prec, size=size, force_dim=force_dim)
+        assert ctrl.obs_dim == obs_dim and ctrl.state_encoder.state_dict()["0.weight"].shape == (256, obs_dim)
+        got = ctrl.predict(state.cuda(), vla.cuda(), cam1.cuda(), cam2.cuda(), forces.cuda(), noise=z.cuda())
+        e = err(got, ref.numpy())
+        print(f"[force_dim {force_dim} B {B} dinov2-{size} {prec}] a_hat err {e:.3e}")
+        assert got.shape == (B, T, 10) and e < TOL[prec], (prec, e)
+        # the tactile vector is really consumed: another m_t gives another a_hat
+        got2 = ctrl.predict(state.cuda(), vla.cuda(), cam1.cuda(), cam2.cuda(), (forces + 1.0).cuda(), noise=z.cuda())
+        assert float((got2 - got).abs().max()) > 1e-4
+        del ctrl
+
+
 @pytest.mark.parametrize("B", [1, 6])
 def test_predict_48_tick_chunks_vs_oracle(controllers, B):
     """The reference's second robot cadence: scripts/franka_inference_eef.py refines 48-tick chunks.  End to end against the oracle in

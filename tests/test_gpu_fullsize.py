@@ -261,3 +261,53 @@ def test_rdt_chunk_feeds_pi_refine_vs_oracle():
     e = float((out.cpu() - ref).abs().max())
     print(f"[chained RDT -> pi_I fp32] max|a_hat - oracle| = {e:.3e}")
     assert out.shape == (2, T, 10) and e < 1e-4, e
+
+
+@pytest.mark.parametrize("force_dim", [3, 64])
+def test_chained_rdt1b_bf16_chunk_feeds_pi_refine_batch32_vs_oracle(rdt1b, force_dim):
+    """BASELINE configs[3] END TO END in the low-precision mode, the quantity the north-star tolerance is stated on: B = 32, RDT-1B bf16 chunk
+    (5-step DPM-Solver++) -> first 16 ticks x 10 EEF dims (`slice_cast`) -> DiffusionController.predict (DINOv2-base, T = 16, injected SDE noise)
+    = a_hat, exactly as bench.py's step chains them (frank_inference_eef.py:495-533, bridge_controller.py:149-182), against
+    oracle.rdt.predict_action -> oracle.controller.predict (fp32 math on the same bf16-rounded RDT weights / inputs / start noise) on episodes 0
+    and 31.  FLAT bar on a_hat: 1e-2, not scaled by the output range — with the bench's unit statistics AND with the non-trivial ones
+    (whose action_range / vla_range ratios amplify whatever error the chunk carries).  force_dim = 64: the 64-d tactile vector of
+    BASELINE.json's workload (bridge_controller.py:25)."""
+    from oracle import controller as oc
+    from residual_controller.bridge_controller import DiffusionController
+    from vlatouch import ops as _ops
+    B, T = 32, 16
+    d = rdt_inputs(B, seed=29)
+    rdt1b.num_inference_timesteps = 5
+    g = np.random.default_rng(31 + force_dim)
+    mk = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
+    cam1, cam2 = mk(0.2 + 0.8 * g.random((B, 3, 224, 224))), mk(0.6 * g.random((B, 3, 224, 224)))
+    state, forces = mk(g.standard_normal((B, 10))), mk(g.standard_normal((B, force_dim)))
+    z = mk(g.standard_normal((10, B, T, 10)))
+    ctrl = cases.build_controller(DiffusionController, precision="bf16", device=DEV, size="base", stats_kind="nontrivial", force_dim=force_dim)
+    chunk = rdt1b.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=d["x0"], return_fp32=True)
+    vla = _ops.slice_cast(chunk, T, 10)
+    assert vla.shape == (B, T, 10) and vla.dtype == torch.float32
+    dev = lambda t: t.to(DEV)
+    stats = {"nontrivial": cases.stats("nontrivial"), "unit": cases.stats("unit")}
+    got = {}
+    for kind, st in stats.items():
+        ctrl.stats = {k: v.to(DEV) for k, v in st.items()}
+        got[kind] = ctrl.predict(dev(state), vla, dev(cam1), dev(cam2), dev(forces), noise=dev(z)).cpu()
+        assert got[kind].shape == (B, T, 10) and torch.isfinite(got[kind]).all()
+    sds = (cases.dino_sd("base"), cases.state_encoder_sd(2 * 768 + 10 + force_dim), cases.si_net_sd("ema"))
+    for b in (0, 31):
+        ref_chunk = _oracle_episode(rdt1b, d, b, 5)                              # [64, 128] fp32
+        e_chunk = float((chunk[b].float().cpu() - ref_chunk).abs().max())
+        one = slice(b, b + 1)
+        for kind, st in stats.items():
+            ref = oc.predict(sds[0], 12, sds[1], sds[2], st, state[one], ref_chunk[None, :T, :10], cam1[one], cam2[one], forces[one], z[:, one])
+            # the same controller fed the ORACLE's chunk: what the pi_I leg alone contributes
+            ctrl.stats = {k: v.to(DEV) for k, v in st.items()}
+            vla_o = vla.clone()
+            vla_o[b] = ref_chunk[:T, :10].to(DEV)
+            pi_only = ctrl.predict(dev(state), vla_o, dev(cam1), dev(cam2), dev(forces), noise=dev(z)).cpu()
+            e_pi = float((pi_only[b] - ref[0]).abs().max())
+            e = float((got[kind][b] - ref[0]).abs().max())
+            print(f"[chain bf16 B=32 force_dim {force_dim} row {b} stats {kind}] chunk err {e_chunk:.3e} (scale {float(ref_chunk.abs().max()):.2f})  "
+                  f"pi_I alone {e_pi:.3e}  a_hat chained {e:.3e} (a_hat scale {float(ref.abs().max()):.2f})")
+            assert e <= 1e-2, (kind, b, e)

@@ -58,6 +58,9 @@ def gelu_ref(y, act):
     (2144, 6144, 2048, "none"),       # 216 tiles on 216 blocks: one tile per block, epilogue entirely in the flat tail
     (70001, 1024, 512, "erf"),        # M % 4 == 1, 4 n-tiles, 4.3 tiles per block
     (16448, 768, 1024, "tanh"),       # 195 tiles on 195 blocks (not a multiple of 8: plain tile order)
+    (65537, 2112, 512, "erf"),        # the smallest K the tile takes (8 k-tiles), M % 256 == 1 (one live row in the last m-tile), N % 256 == 64 (one wave column live)
+    (33023, 1088, 512, "tanh"),       # M % 256 == 255 (one dead row), N % 256 == 64, K = 512
+    (33023, 2112, 576, "none"),       # the same edges at an odd k-tile count
 ])
 def test_persistent_tile_row_major_16bit(dev, dtype, M, N, K, act):
     from vlatouch import ops, _lib as L
@@ -105,7 +108,8 @@ def _untile(kv, T):
     return k, v
 
 
-@pytest.mark.parametrize("M,K,mode", [(70001, 512, "meansq"), (13122, 2048, "var"), (139968 // 4, 2048, "meansq"), (4374, 2048, "meansq")])
+@pytest.mark.parametrize("M,K,mode", [(70001, 512, "meansq"), (13122, 2048, "var"), (139968 // 4, 2048, "meansq"), (4374, 2048, "meansq"),
+                                      (65537, 512, "var"), (33023, 512, "meansq")])      # M % 256 in {1, 255} at the smallest K
 def test_persistent_tile_fused_kv_projection(dev, M, K, mode):
     from vlatouch import ops, _lib as L
     N, H = 4096, 32
@@ -151,6 +155,8 @@ def test_persistent_tile_fused_kv_projection(dev, M, K, mode):
     (33000, 2048, 576, False),            # nk = 9 (buffer parity flips per tile)
     (16448, 768, 3072, True),             # 65 x 3 = 195 tiles: one block per tile, a grid that is not a multiple of 8 (plain tile order), ragged last m-tile
     (16448, 768, 768, True),              # DINOv2-B out-projection: one round at K = 768, a shape only the persistent kernel takes (vt_gemm_pt_extra_shape)
+    (65537, 1088, 512, True),             # smallest K, M % 256 == 1, N % 256 == 64
+    (33023, 2112, 512, False),            # M % 256 == 255, N % 256 == 64
 ])
 def test_persistent_tile_fp32_residual_kind(dev, dtype, M, N, K, inplace):
     """R32 kind: C (fp32) = residual + colscale * (A W^T + bias) — the LayerScale + residual epilogue of the ViT out-projection / fc2 — against

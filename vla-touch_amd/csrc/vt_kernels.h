@@ -77,7 +77,8 @@ int vt_k_actnorm(const float* in, float* out, const float* mins, const float* ma
 int vt_k_pad_cols(const float* in, int cin, void* out, int odt, int cout, long rows, hipStream_t s);
 int vt_k_place_cols(const void* src, int sdt, long lds_, void* out, int odt, long ldo, int off, int rows, int cols, hipStream_t s);
 int vt_k_bcast_row(const float* vec, float* out, long row_stride, int B, int D, hipStream_t s);
-int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s);
+int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s,
+                  float* flags_copy = nullptr);   // flags_copy: optional second [4] output written by the same kernel
 int vt_k_patchify(const void* img, int is_u8, int nhwc, int B, int res, int grid_, int kpad, const float* flags, void* out, int odt, hipStream_t s);
 int vt_k_lstm_cell(const float* gi, const float* gh, float* h, float* c, int B, int H, hipStream_t s);
 int vt_k_axpby3(float* x, const void* m0, const void* m1, int mdt, float a, float b0, float b1, long n, hipStream_t s);

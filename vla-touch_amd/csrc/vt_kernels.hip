@@ -4,6 +4,7 @@
 // image statistics + patchify (one HBM read of the frames), the SDE update, action (de)normalisation
 // and the small glue kernels of the U-Net / LSTM drivers.
 #include <stdlib.h>
+#include <type_traits>
 #include "vt_common.h"
 #include "vt_kernels.h"
 
@@ -434,7 +435,11 @@ __global__ void swiglu_kernel(T* __restrict__ h, long ld, long rows, int F) {
 #pragma unroll
   for (int k = 0; k < V; ++k) {
     const float x1 = Elem<T>::to_f(av[k]), x2 = Elem<T>::to_f(bv[k]);
-    av[k] = Elem<T>::from_f(x1 * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x1)) * x2);
+    float g = x1 * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x1)) * x2;
+    // IEEE fp16 storage (the low-precision DINOv2 mode): the gated product of two fp16 values can leave the fp16 range (outlier tokens of real giant
+    // checkpoints); saturate instead of producing inf, which fc2 would turn into NaN for the whole row (inf - inf across the k range)
+    if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) g = fminf(fmaxf(g, -65504.0f), 65504.0f);
+    av[k] = Elem<T>::from_f(g);
   }
   *reinterpret_cast<uint4*>(p1) = a;
 }
@@ -543,7 +548,8 @@ __global__ __launch_bounds__(256) void imgstat_partial_kernel(const TI* __restri
 }
 // flags[0] = pixel scale (1 or 1/255), flags[1] = 1.0 if ImageNet normalisation applies (visual_encoder.py:78,100).  One wave: lane l folds partials l, l + 64, ...
 // (a single lane walking all of them was 19 us)
-__global__ __launch_bounds__(64) void imgstat_final_kernel(const float* __restrict__ part, int nparts, long n, float pre_scale, int norm_mode, float* __restrict__ flags) {
+__global__ __launch_bounds__(64) void imgstat_final_kernel(const float* __restrict__ part, int nparts, long n, float pre_scale, int norm_mode, float* __restrict__ flags,
+                                                           float* __restrict__ flags_copy) {
   if (blockIdx.x != 0) return;
   float mx = -3.4e38f;
   double sm = 0.0;
@@ -564,6 +570,7 @@ __global__ __launch_bounds__(64) void imgstat_final_kernel(const float* __restri
   flags[1] = norm_mode == VT_IMGNORM_AUTO ? (mean < 0.5f ? 0.f : 1.f) : (norm_mode == VT_IMGNORM_ON ? 1.f : 0.f);
   flags[2] = mx;
   flags[3] = mean;
+  if (flags_copy) { flags_copy[0] = flags[0]; flags_copy[1] = flags[1]; flags_copy[2] = mx; flags_copy[3] = mean; }     // the caller's copy (no runtime copy kernel)
 }
 
 // ------------------------------------------------------------------ patchify: frames -> A[b*np + p][c*196 + i*14 + j] (K padded)
@@ -753,11 +760,11 @@ int vt_k_bcast_row(const float* vec, float* out, long row_stride, int B, int D, 
   return vt_check_launch();
 }
 
-int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s) {
+int vt_k_imgstats(const void* img, int is_u8, long n, float pre_scale, int norm_mode, float* part, float* flags, hipStream_t s, float* flags_copy) {
   const int nb = 256;                  // the callers' partials buffers hold 256 x 2 floats per camera
   if (is_u8) hipLaunchKernelGGL((imgstat_partial_kernel<uint8_t>), dim3(nb), dim3(256), 0, s, (const uint8_t*)img, n, part);
   else hipLaunchKernelGGL((imgstat_partial_kernel<float>), dim3(nb), dim3(256), 0, s, (const float*)img, n, part);
-  hipLaunchKernelGGL(imgstat_final_kernel, dim3(1), dim3(64), 0, s, part, nb, n, pre_scale, norm_mode, flags);
+  hipLaunchKernelGGL(imgstat_final_kernel, dim3(1), dim3(64), 0, s, part, nb, n, pre_scale, norm_mode, flags, flags_copy);
   return vt_check_launch();
 }
 

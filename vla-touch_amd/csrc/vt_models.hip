@@ -142,9 +142,8 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
     float* part = (float*)(ws + w.part) + c * 512;
     float* flags = (float*)(ws + w.flags) + c * 8;
     const long n = (long)B * 3 * res * res;
-    CK(vt_wrap(vt_k_imgstats(imgs[c], is_u8, n, pre_scale, norm_mode, part, flags, s), "dino imgstats"));
+    CK(vt_wrap(vt_k_imgstats(imgs[c], is_u8, n, pre_scale, norm_mode, part, flags, s, flags_out ? flags_out + c * 4 : nullptr), "dino imgstats"));
     CK(vt_wrap(vt_k_patchify(imgs[c], is_u8, nhwc, B, res, g, d.kpad, flags, ws + w.apatch + (size_t)c * B * np * d.kpad * a, d.adt, s), "dino patchify"));
-    if (flags_out && hipMemcpyAsync(flags_out + c * 4, flags, 16, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "flags copy");
   }
   // 2. patch-embed GEMM, one group per image, + position embedding (shared residual) -> fp32 tokens rows 1..np
   {

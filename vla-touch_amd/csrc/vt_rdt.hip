@@ -151,11 +151,17 @@ constexpr int RDT_MAX_SPLITK = 16;
 constexpr int RDT_SK_CNT = 4096;
 struct RWs {
   size_t lang_c, img_c, tmpA, tmpB, state_tok, freq_emb, t_emb, emb_tmp, sin, kv_lang, kv_img, x, xn, qkv, q, att, hid, sa_in, sa_tmpA, sa_tmpB,
-      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, sk_cnt, rs_part, total;
+      out_tok, x0_cur, x0_prev, noisy, noisy_a, slab, sk_cnt, rs_part, kv_small, total;
   size_t kv_lang_blk, kv_img_blk;   // bytes per block
   size_t slab_bytes;                // split-K scratch of the small-batch Linears (0 when M is large enough without it)
   size_t attn_part; int attn_parts; // key-range parts of the cached cross-attention at small batch (1 = off)
 };
+// the fused K | V projection of a condition with R rows, as cache_cond launches it (pointers left null: only shapes and dtypes decide the path)
+VtGemmParams cond_kv_params(const vt_rdt_desc& d, int R) {
+  VtGemmParams p = lin(nullptr, d.adt, d.hidden, nullptr, d.cdt, d.hidden, nullptr, nullptr, d.adt, d.hidden, R, 2 * d.hidden, d.hidden, VT_ACT_NONE);
+  p.cmap = 3; p.cmap_T = lpad64(R) / 64;
+  return p;
+}
 RWs rcarve(const vt_rdt_s* h, int B, int L) {
   const vt_rdt_desc& d = h->d;
   const int a = es(d.adt), D = d.hidden, N = d.horizon + 3, Li = d.img_len;
@@ -165,6 +171,11 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.img_c = take((size_t)B * Li * D * a);
   const size_t rows = (size_t)B * (Li > L ? Li : L);
   w.tmpA = take(rows * D * a); w.tmpB = take(rows * D * a);
+  // row-major [R][2D] scratch of the K | V product of a condition that falls off the large-GEMM path (few rows: the language tokens at batch 1..3,
+  // every condition of the tiny test configs) — its own buffer: 2 R D elements do not fit tmpA when 2 R > max(Li, L) * B
+  { size_t rs = 0;
+    if (d.adt == VT_BF16) for (int R : {B * L, B * Li}) if (!vt_gemm_can_fuse_headnorm(cond_kv_params(d, R)) && (size_t)R > rs) rs = (size_t)R;
+    w.kv_small = take(rs * 2 * D * a); }
   w.state_tok = take((size_t)B * D * a); w.freq_emb = take((size_t)B * D * a); w.t_emb = take((size_t)B * D * a);
   w.emb_tmp = take((size_t)B * D * a); w.sin = take((size_t)B * 256 * a);
   const int n_lang_blk = (d.depth + 1) / 2, n_img_blk = d.depth / 2;
@@ -232,10 +243,16 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
   const bool small = c.w.slab_bytes > 0 && !vt_gemm_fast_eligible(p) && p.M <= 512 && p.K >= 512 && (p.K % 64) == 0 && (p.N % 4) == 0 && !p.hn_w0 &&
                      !p.hn_w1 && p.groups == 1 && p.taps == 0 && S >= 2 && (size_t)S * p.M * p.N * 4 <= c.w.slab_bytes;
   if (!small) {
+    // producer side of the RMSNorm hand-off: decided on THIS launch's parameters (the per-run switch c.fuse_norm only says that block 0 qualifies):
+    // a Linear that would not take the weights-in-registers tile with the hand-off fields set keeps the plain path, and the caller's row-norm kernel runs
     if (c.fuse_norm && pw_fuse && next_norm && xn_done && p.residual == p.C && p.c_dtype == VT_F32 && p.N == c.h->d.hidden && p.act == VT_ACT_NONE && p.ldc == p.N) {
-      p.xn_out = c.ws + c.w.xn; p.xn_ld = p.N; p.xn_gain = next_norm; p.xn_part = (float*)(c.ws + c.w.rs_part);
-      *xn_done = true;
-      c.rs_pending = true;
+      VtGemmParams q = p;
+      q.xn_out = c.ws + c.w.xn; q.xn_ld = p.N; q.xn_gain = next_norm; q.xn_part = (float*)(c.ws + c.w.rs_part);
+      if (vt_gemm_fast_eligible(q) && vt_gemm_pw_eligible(q)) {
+        p = q;
+        *xn_done = true;
+        c.rs_pending = true;
+      }
     }
     return vt_wrap(vt_gemm_launch(p, c.s), what);
   }
@@ -319,20 +336,21 @@ int cache_cond(RCtx& c) {
       // large-GEMM path; small shapes go row-major through tmpA / tmpB and the retile kernels.
       const int T = lpad64(c.B * Lc) / 64;
       // one launch per layer: K | V fused (N = 2D), both halves of the tile stream written from ONE pass over the condition rows
-      VtGemmParams pkv = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
-      pkv.cmap = 3; pkv.cmap_T = T;
+      VtGemmParams pkv = cond_kv_params(d, c.B * Lc);
+      pkv.A = src; pkv.W = b.ckv_w; pkv.bias = b.ckv_b; pkv.C = kv;
       if (fuse_headnorm(pkv, b.ckn, D, nullptr, D, d.rms_mode)) {
         CK(vt_wrap(vt_gemm_launch(pkv, c.s), "rdt cond kv"));
       } else {
         // small condition (the language tokens below 128 rows: batch 1..3): ONE K | V product (N = 2D) on the split-K path of the denoise loop's
-        // Linears, k_norm folded into its slab reduction, row-major [rows][2D] into tmpA; then one retile launch.  (Two 32-row GEMMs walking
+        // Linears, k_norm folded into its slab reduction, row-major [rows][2D] into its own scratch (kv_small, sized by rcarve with the same test); then one retile launch.  (Two 32-row GEMMs walking
         // K = 2048 on 32 blocks each + head norm + two retile launches were 75 us per layer at batch 1; this is 20.)
         const int rows = c.B * Lc;
-        VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, c.ws + c.w.tmpA, d.adt, 2 * D, rows, 2 * D, D, VT_ACT_NONE);
+        char* kvs = c.ws + c.w.kv_small;
+        VtGemmParams pk = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kvs, d.adt, 2 * D, rows, 2 * D, D, VT_ACT_NONE);
         bool folded = false;
         CK(rgemm(c, pk, "rdt cond kv (small)", b.ckn, D, nullptr, D, &folded));
-        if (!folded) CK(vt_k_headnorm(c.ws + c.w.tmpA, d.adt, 2 * D, d.heads, (long)rows, b.ckn, 1e-6f, d.rms_mode, c.s));
-        CK(vt_wrap(vt_k_retile_kv(c.ws + c.w.tmpA, c.ws + c.w.tmpA + (size_t)D * c.a, 2 * D, kv, rows, T, d.heads, c.s), "rdt cond retile"));
+        if (!folded) CK(vt_k_headnorm(kvs, d.adt, 2 * D, d.heads, (long)rows, b.ckn, 1e-6f, d.rms_mode, c.s));
+        CK(vt_wrap(vt_k_retile_kv(kvs, kvs + (size_t)D * c.a, 2 * D, kv, rows, T, d.heads, c.s), "rdt cond retile"));
       }
     } else {
       VtGemmParams p = lin(src, d.adt, D, b.ckv_w, d.cdt, D, b.ckv_b, kv, d.adt, 2 * D, c.B * Lc, 2 * D, D, VT_ACT_NONE);
@@ -364,11 +382,17 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
   return attn(c, c.ws + c.w.q, D, kv, kv + (size_t)D * a, 2 * D, N, Lc, lang ? lang_mask : nullptr, c.ws + c.w.att);
 }
 
-// the Linear about to run reads c.w.xn: if that is the un-normalised x * gain of a fused RMSNorm hand-off, it applies the rows' rstd itself
-void take_rstd(RCtx& c, VtGemmParams& p) {
-  if (!c.rs_pending) return;
+// the Linear about to run reads c.w.xn: if that is the un-normalised x * gain of a fused RMSNorm hand-off, it applies the rows' rstd itself — provided it
+// takes the weights-in-registers tile (the only kernel with the consumer side); otherwise the row-norm kernel rebuilds xn from the fp32 stream
+// (complete: the producer wrote it) with the same gain, and the Linear runs plain.  `gain` = the norm weight the producer was given.
+int take_rstd(RCtx& c, VtGemmParams& p, const float* gain) {
+  if (!c.rs_pending) return VT_OK;
   c.rs_pending = false;
-  p.rs_part = (const float*)(c.ws + c.w.rs_part); p.rs_n = 2 * (c.h->d.hidden / 128); p.rs_inv_k = 1.0f / (float)c.h->d.hidden; p.rs_eps = 1e-6f;
+  VtGemmParams q = p;
+  q.rs_part = (const float*)(c.ws + c.w.rs_part); q.rs_n = 2 * (c.h->d.hidden / 128); q.rs_inv_k = 1.0f / (float)c.h->d.hidden; q.rs_eps = 1e-6f;
+  if (q.c_dtype != VT_F32 && vt_gemm_fast_eligible(q) && vt_gemm_pw_eligible(q)) { p = q; return VT_OK; }
+  const vt_rdt_desc& d = c.h->d;
+  return vt_k_rownorm((const float*)(c.ws + c.w.x), VT_F32, d.hidden, c.ws + c.w.xn, d.adt, d.hidden, gain, nullptr, p.M, d.hidden, 1e-6f, d.rms_mode, c.s);
 }
 
 // blocks + final layer on the fp32 stream x [B*(horizon+3)][D]; writes out_tok [B*(horizon+3)][out_dim] (adt)
@@ -398,7 +422,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm1, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.qkv_w, d.cdt, D, b.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE, b.qkv_wp);
-      take_rstd(c, p);
+      CK(take_rstd(c, p, b.norm1));
       bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
       bool folded = false;
       CK(rgemm(c, p, "rdt qkv", fused ? nullptr : b.qn, D, b.kn, 2 * D, &folded));
@@ -415,7 +439,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.cq_w, d.cdt, D, b.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE, b.cq_wp);
-      take_rstd(c, p);
+      CK(take_rstd(c, p, b.norm2));
       bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       bool folded = false;
       CK(rgemm(c, p, "rdt cross q", fused ? nullptr : b.cqn, D, nullptr, D, &folded));
@@ -429,7 +453,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, b.fc1_wp);
-      take_rstd(c, p);
+      CK(take_rstd(c, p, b.norm3));
       CK(rgemm(c, p, "rdt fc1")); }
     { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.fc2_wp);
       p.residual = x; p.ldr = D;
@@ -469,10 +493,11 @@ __global__ void add_pos_kernel(const void* cond, const void* pos, void* out, int
   else ((float*)out)[i] = ((const float*)cond)[i] + ((const float*)pos)[pl];
 }
 
-// in-place round of an fp32 buffer to the activation dtype's grid (bf16 mode: noisy_action lives in bf16, rdt_runner.py:137-139,160)
-__global__ void round_bf16_kernel(float* x, long n) {
+// dst = src rounded to the activation dtype's grid (bf16 mode: noisy_action lives in bf16, rdt_runner.py:137-139,160; fp32 mode: a plain copy) —
+// the solver state's first value, taken from the caller's start noise in one kernel (no runtime copy kernel in the step)
+__global__ void take_xinit_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int is_bf16) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] = bf2f(f2bf(x[i]));
+  if (i < n) dst[i] = is_bf16 ? bf2f(f2bf(src[i])) : src[i];
 }
 
 // sa_in[b][t] = cat(noisy[b][t] (adt copy of the fp32 master), mask[b])   (rdt_runner.py:148)
@@ -505,7 +530,7 @@ __global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N,
 
 // noisy = round_adt(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163)
 __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, const void* x0p, float a, float b0, float b1, const void* mask, int last,
-                                  int B, int Hh, int S, int is_bf16, int sample_pred, float alpha_s, float sigma_s, void* x0_store) {
+                                  int B, int Hh, int S, int is_bf16, int sample_pred, float alpha_s, float sigma_s, void* x0_store, float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
@@ -519,6 +544,7 @@ __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, con
   if (last) v *= is_bf16 ? bf2f(((const bf16_t*)mask)[(long)b * S + c]) : ((const float*)mask)[(long)b * S + c];
   if (last && is_bf16) v = bf2f(f2bf(v));
   noisy[i] = v;
+  if (out) out[i] = v;                                              // the last step also writes the caller's buffer
 }
 
 inline dim3 g1(long n) { return dim3((unsigned)((n + 255) / 256)); }
@@ -591,8 +617,8 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
   CK(cache_cond(c));
   CK(embed(c, ctrl_freqs, 0.f, h->f_w1, h->f_b1, h->f_w2, h->f_b2, c.w.freq_emb));
   const long n = (long)B * Hh * S;
-  if (hipMemcpyAsync(c.ws + c.w.noisy, x_init, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "x_init copy");
-  if (bf) { hipLaunchKernelGGL(round_bf16_kernel, g1(n), dim3(256), 0, s, (float*)(c.ws + c.w.noisy), n); CK(vt_check_launch()); }
+  hipLaunchKernelGGL(take_xinit_kernel, g1(n), dim3(256), 0, s, x_init, (float*)(c.ws + c.w.noisy), n, bf);
+  CK(vt_check_launch());
   char* x0_cur = c.ws + c.w.x0_cur;
   char* x0_prev = c.ws + c.w.x0_prev;
   for (int k = 0; k < n_steps; ++k) {
@@ -610,10 +636,9 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
     const float* cf = coef + 5 * k;
     const bool last = k == n_steps - 1;
     hipLaunchKernelGGL(dpm_update_kernel, g1(n), dim3(256), 0, s, (float*)(c.ws + c.w.noisy), (const void*)x0_cur, (const void*)(cf[2] != 0.f ? x0_prev : nullptr), cf[0], cf[1],
-                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, bf, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur));
+                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, bf, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
     CK(vt_check_launch());
     char* t = x0_cur; x0_cur = x0_prev; x0_prev = t;
   }
-  if (hipMemcpyAsync(out, c.ws + c.w.noisy, n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "out copy");
   return VT_OK;
 }

@@ -26,6 +26,25 @@ from residual_controller.bridge.networks.conditional_unet_1D_si import Interpola
 _GAMMA = {"2^0.5*t(t-1)": 0, "(2t(t-1))^0.5": 1, "(1-t)^2(2t)^0.5": 2}
 _EPS = {"1-t": 0, "t(t-1)": 1, "1-sqrt(t)": 2, "1-t^2": 3, "0": 4}
 
+_R2 = 1.4142       # the reference's literal for sqrt(2) (bridge_model.py:75-100), kept to the digit: goldens compare schedules at 1e-6
+_TINY = 1e-4       # its guard against 1/0 at the interval ends
+# epsilon_type -> eps(t)
+_EPSILON_OF_T = {
+    "1-t": lambda t, si: 1.0 - t,
+    "t(t-1)": lambda t, si: t - t * t,
+    "1-sqrt(t)": lambda t, si: 1.0 - t.sqrt(),
+    "1-t^2": lambda t, si: 1.0 - t * t,
+    "0": lambda t, si: torch.zeros_like(t),
+}
+# gamma_type -> (gamma(t), d gamma / dt, the guarded denominator whose reciprocal — clamped to [0, gamma_inv_max] — is gamma_inv(t))
+_GAMMA_OF_T = {
+    "2^0.5*t(t-1)": lambda t, si: (_R2 * t * (1 - t), _R2 * (1 - 2 * t), _R2 * t * (1 - t) + _TINY),
+    "(2t(t-1))^0.5": lambda t, si: (_R2 * (t * (1 - t)).sqrt(), (1 - 2 * t) / (2 * (t - t * t) + _TINY).sqrt(), _R2 * (t * (1 - t) + _TINY).sqrt()),
+    "(1-t)^2(2t)^0.5": lambda t, si: (_R2 * (1 - t) ** 2 * t.sqrt(),
+                                      _R2 * (2 * (t - 1) * t.sqrt() + (1 - t) ** 2 / (2.0 * (t + _TINY).sqrt())),
+                                      _R2 * (1 - t) ** 2 * t.sqrt() + _TINY),
+}
+
 
 class StochasticInterpolants:
     def __init__(self, model_args=None, precision: Optional[str] = None):
@@ -52,46 +71,28 @@ class StochasticInterpolants:
         self._sampler = None
         self.sde_type = model_args['sde_type'] if 'sde_type' in model_args else 'vs'
 
-    # ---- schedules (host-side scalar definitions; the sampler evaluates the same formulas per step in C)
+    # ---- schedules: thin string-keyed lookups into the tables below (the reference's four if/elif methods, bridge_model.py:59-101, as data).
+    #      Dead on the sampling path — csrc/vt_unet.hip (si_schedule) evaluates the same formulas per SDE step from the codes in _GAMMA / _EPS;
+    #      kept because they are public methods of the reference class.  Unknown key -> NotImplementedError, as there.
+    def _schedule(self, table, key, t):
+        try:
+            f = table[key]
+        except KeyError:
+            raise NotImplementedError(key) from None
+        return f(torch.as_tensor(t) if not torch.is_tensor(t) else t, self)
+
     def epsilon(self, t):
-        if self.epsilon_type == 't(t-1)':
-            return t * (1 - t)
-        elif self.epsilon_type == '1-t':
-            return (1 - t) * 1.0
-        elif self.epsilon_type == '1-sqrt(t)':
-            return 1 - torch.sqrt(t)
-        elif self.epsilon_type == '1-t^2':
-            return 1 - torch.pow(t, 2)
-        elif self.epsilon_type == '0':
-            return t * 0.0
-        raise NotImplementedError
+        return self._schedule(_EPSILON_OF_T, self.epsilon_type, t)
 
     def gamma(self, t):
-        if self.gamma_type == '(2t(t-1))^0.5':
-            return 1.4142 * torch.sqrt(t * (1 - t))
-        elif self.gamma_type == '2^0.5*t(t-1)':
-            return 1.4142 * t * (1 - t)
-        elif self.gamma_type == '(1-t)^2(2t)^0.5':
-            return 1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t)
-        raise NotImplementedError
+        return self._schedule(_GAMMA_OF_T, self.gamma_type, t)[0]
 
     def gamma_der(self, t):
-        if self.gamma_type == '(2t(t-1))^0.5':
-            return (1 - 2 * t) / torch.sqrt(2 * (t - torch.pow(t, 2)) + 1e-4)
-        if self.gamma_type == '2^0.5*t(t-1)':
-            return 1.4142 * (1 - 2 * t)
-        elif self.gamma_type == '(1-t)^2(2t)^0.5':
-            return 1.4142 * (2 * (t - 1) * torch.sqrt(t) + torch.pow((1 - t), 2.0) / (2.0 * torch.sqrt(t + 1e-4)))
-        raise NotImplementedError
+        return self._schedule(_GAMMA_OF_T, self.gamma_type, t)[1]
 
     def gamma_inv(self, t):
-        if self.gamma_type == '(2t(t-1))^0.5':
-            return torch.clamp(1 / (1.4142 * torch.sqrt(t * (1 - t) + 1e-4)), 0.0, self.gamma_inv_max)
-        elif self.gamma_type == '2^0.5*t(t-1)':
-            return torch.clamp(1 / (1.4142 * t * (1 - t) + 1e-4), 0.0, self.gamma_inv_max)
-        elif self.gamma_type == '(1-t)^2(2t)^0.5':
-            return torch.clamp(1 / (1.4142 * torch.pow((1 - t), 2.0) * torch.sqrt(t) + 1e-4), 0.0, self.gamma_inv_max)
-        raise NotImplementedError
+        g_floor = self._schedule(_GAMMA_OF_T, self.gamma_type, t)[2]
+        return (1.0 / g_floor).clamp(0.0, self.gamma_inv_max)
 
     # ---- sampling
     def _sampler_engine(self, nets, device):
@@ -107,7 +108,7 @@ class StochasticInterpolants:
             self._sampler = (key, eng)
         return self._sampler[1]
 
-    def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise, record=True):
+    def _run(self, nets, sde_code, x_initial, cond, delta_t, score_weight, direction, noise, record=True, own_x=False):
         if direction not in ('forward', 'backward'):
             raise NotImplementedError
         if self.gamma_type not in _GAMMA or self.epsilon_type not in _EPS:
@@ -120,25 +121,27 @@ class StochasticInterpolants:
         eng = self._sampler_engine(nets, dev)
         res = eng.sample(x_initial, cond, noise, n_steps, float(self.d), record=record,
                          gamma_type=_GAMMA[self.gamma_type], epsilon_type=_EPS[self.epsilon_type], sde_type=sde_code,
-                         backward=direction == 'backward', score_weight=float(score_weight))
+                         backward=direction == 'backward', score_weight=float(score_weight), own_x0=own_x)
         if not record:       # the hot path: no trajectory buffer, no per-step copies
             return res, None
         xT, traj = res
         return xT, [traj[i] for i in range(traj.shape[0])]
 
-    def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True):
-        return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise, record)
+    def sde_vs(self, v_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True, _own_x=False):
+        return self._run(("v_net", "s_net"), 0, x_initial, cond, delta_t, score_weight, direction, noise, record, _own_x)
 
-    def sde_bs(self, b_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True):
-        return self._run(("b_net", "s_net"), 1, x_initial, cond, delta_t, score_weight, direction, noise, record)
+    def sde_bs(self, b_net=None, s_net=None, x_initial=None, cond=None, delta_t=0.025, score_weight=1.0, direction='forward', noise=None, record=True, _own_x=False):
+        return self._run(("b_net", "s_net"), 1, x_initial, cond, delta_t, score_weight, direction, noise, record, _own_x)
 
-    def sample(self, x_prior, cond, diffuse_step=10, recod_traj=False, noise=None):
-        """x_prior (batch, T, dim) normalised prior actions, cond (batch, obs_dim) -> refined normalised actions."""
+    def sample(self, x_prior, cond, diffuse_step=10, recod_traj=False, noise=None, _own_prior=False):
+        """x_prior (batch, T, dim) normalised prior actions, cond (batch, obs_dim) -> refined normalised actions.
+        `_own_prior=True` (extension, used by DiffusionController.predict whose x_prior is a temporary): the integrator may run in place
+        on x_prior instead of on a copy — one runtime copy kernel less per step."""
         with torch.no_grad():
             if self.sde_type == 'vs':
-                x_target, x_target_traj = self.sde_vs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj)
+                x_target, x_target_traj = self.sde_vs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj, _own_x=_own_prior)
             elif self.sde_type == 'bs':
-                x_target, x_target_traj = self.sde_bs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj)
+                x_target, x_target_traj = self.sde_bs(x_initial=x_prior, cond=cond, delta_t=float(1.0 / diffuse_step), noise=noise, record=recod_traj, _own_x=_own_prior)
             else:
                 raise NotImplementedError
         if recod_traj:

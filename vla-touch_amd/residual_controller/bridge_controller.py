@@ -117,7 +117,7 @@ class DiffusionController:
                 obs_cond = self.encode_observation(state, images_cam1, images_cam2, forces)
             vla_actions_n = normalize_actions(torch.as_tensor(vla_actions).to(self.device), self.stats, 'vla')
             refined_actions_n = self.diffusion_model.sample(x_prior=vla_actions_n, cond=obs_cond,
-                                                            diffuse_step=self.diffusion_steps, noise=noise)
+                                                            diffuse_step=self.diffusion_steps, noise=noise, _own_prior=True)
             return denormalize_actions(refined_actions_n, self.stats, 'expert')
 
     def train(self):

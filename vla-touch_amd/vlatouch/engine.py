@@ -203,10 +203,14 @@ class UNetEngine:
 
     def sample(self, x0: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], n_steps: int, beta_max: float,
                record: bool = False, gamma_type: int = 0, epsilon_type: int = 0, sde_type: int = 0, backward: bool = False,
-               score_weight: float = 1.0):
-        """Velocity-score / drift-score SDE from x0 (normalised actions).  Returns xT (and the n_steps+1 states)."""
+               score_weight: float = 1.0, own_x0: bool = False):
+        """Velocity-score / drift-score SDE from x0 (normalised actions).  Returns xT (and the n_steps+1 states).  The integrator runs in place on
+        a copy of x0 — or on x0 itself when the caller gives it away (`own_x0`: a temporary already on the device in fp32, contiguous)."""
         B, T, D = x0.shape
-        x = x0.to(self.device, torch.float32).clone().contiguous()
+        if own_x0 and x0.device == self.device and x0.dtype == torch.float32 and x0.is_contiguous():
+            x = x0
+        else:
+            x = x0.to(self.device, torch.float32).clone().contiguous()
         cond = cond.to(self.device, torch.float32).contiguous()
         if noise is not None:
             noise = noise.to(self.device, torch.float32).contiguous()
@@ -291,9 +295,19 @@ class DinoEngine:
 
     def repack(self) -> None:
         """Rebuild the fragment-packed fc1 copy from `self._weights` (after they were overwritten in place, e.g. by the one-time broadcast of rank 0's
-        weights, vlatouch/dist.py)."""
+        weights, vlatouch/dist.py).
+
+        INVARIANT: `self._packed` (a second, fragment-ordered copy of every fc1 weight) is DERIVED from `self._weights`; the remainder rows of the
+        token matrix and the CLS-only last block read it while all other rows read `_weights`.  Any in-place write to `_weights` must be followed
+        by `repack()` — use `update_weights()` for that, never write the tensors and walk away."""
         if getattr(self, "_packed", None) is not None:
             L.check(L.lib().vt_dino_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_dino_set_packed")
+
+    def update_weights(self, fn) -> None:
+        """The one sanctioned way to change weights in place: `fn(list_of_packed_device_tensors)` mutates them (checkpoint reload into the same
+        tensors, a broadcast, a fine-tuning step), then every derived copy is rebuilt."""
+        fn(self._weights)
+        self.repack()
 
     def pos_patch(self, grid: int) -> torch.Tensor:
         """Position embeddings of the patch tokens for a grid x grid image: input-independent, so the bicubic

@@ -107,6 +107,11 @@ class RdtEngine:
         if self._packed is not None:
             L.check(L.lib().vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_rdt_set_packed")
 
+    def update_weights(self, fn):
+        """In-place change of the packed weights through `fn(self._weights)`, followed by `repack()` (the derived copies never go stale)."""
+        fn(self._weights)
+        self.repack()
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):

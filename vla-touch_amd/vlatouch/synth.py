@@ -363,17 +363,18 @@ def unit_stats():
     return dict(action_mins=z.clone(), action_maxs=o.clone(), vla_mins=z.clone(), vla_maxs=o.clone(), action_range=o.clone(), vla_range=o.clone())
 
 
-def build_controller(cls, precision: str, device="cuda:0", size: str = "small", stats=None, **kw):
+def build_controller(cls, precision: str, device="cuda:0", size: str = "small", stats=None, force_dim: int = 3, **kw):
     """A DiffusionController (the mirror class `cls`) filled with the deterministic synthetic weights the goldens were made
     with (no checkpoints exist offline): raw `net` params = salt "", EMA shadow params = salt "ema" — a sampler that
-    forgets to run under the EMA weights fails the goldens."""
+    forgets to run under the EMA weights fails the goldens.  `force_dim` = width of the tactile vector m_t (reference default 3 =
+    the marker tracker's force estimate, bridge_controller.py:25; BASELINE's synthetic workload names a 64-d tactile vector)."""
     c = DINOV2_CONFIGS[size]
     ctrl = cls(state_dim=10, hidden_dim=256, image_model_path=f"facebook/dinov2-{size}", diffusion_steps=10, device=device,
-               model_args=dict(MODEL_ARGS), use_force=True, force_dim=3, precision=precision,
+               model_args=dict(MODEL_ARGS), use_force=True, force_dim=force_dim, precision=precision,
                image_state_dict=torch_state_dict(dinov2_shapes(c["hidden"], c["layers"]), prefix=f"dinov2-{size}."), **kw)
     latent = c["hidden"]
-    ctrl.state_encoder.load_state_dict(torch_state_dict(state_encoder_shapes(2 * latent + 13), prefix="state_encoder."))
-    ctrl.force_decoder.load_state_dict(torch_state_dict(force_decoder_shapes(), prefix="force_decoder."))
+    ctrl.state_encoder.load_state_dict(torch_state_dict(state_encoder_shapes(2 * latent + 10 + force_dim), prefix="state_encoder."))
+    ctrl.force_decoder.load_state_dict(torch_state_dict(force_decoder_shapes(force_dim=force_dim), prefix="force_decoder."))
     ctrl.diffusion_model.net.load_state_dict(torch_state_dict(si_net_shapes(10, 256), prefix="si.", salt=""))
     ema = torch_state_dict(si_net_shapes(10, 256), prefix="si.", salt="ema")
     ctrl.diffusion_model.ema.load_state_dict({"decay": 0.75, "num_updates": 0, "collected_params": None,
