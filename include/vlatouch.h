@@ -233,6 +233,9 @@ size_t vt_rdt_workspace_bytes(vt_rdt_t h, int B, int lang_len);
 /* bounds[depth] (host): per block an upper bound of |q . k| * scale of its cross-attention (8 max|q_norm.weight| max|k_norm.weight| for the
  * mean-square RMSNorm of blocks.py:86-87; 0 = none) -> the cached cross-attention uses a fixed-maximum softmax where the bound is <= 40. */
 int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n);
+/* 16-bit mode only: 1 (default) = DPM-Solver++ state, x0 predictions and the final projection in fp32 between network evaluations; 0 = the
+ * reference's bf16 rounding points (models/rdt_runner.py:137-139,160: `noisy_action.to(dtype)` after every scheduler step). */
+int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state);
 size_t vt_rdt_packed_bytes(vt_rdt_t h);
 int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream);
 /* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the

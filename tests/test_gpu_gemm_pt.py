@@ -190,49 +190,61 @@ def test_persistent_tile_fp32_residual_kind(dev, dtype, M, N, K, inplace):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("mode", ["meansq", "var"])
 @pytest.mark.parametrize("M,N2,hn", [(2144, 6144, True), (2144, 2048, False), (2100, 2048, True)])
-def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn):
+def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn, mode):
     """The fused RMSNorm hand-off of the per-denoise-step Linears (vt_gemm.h xn_out / rs_part): residual Linear -> [norm] -> Linear with the norm launch
-    replaced by (x * gain, sums of squares) out of the first epilogue and a row scale in the second, against the three-launch form and torch fp32."""
+    replaced by (x * gain, (sum of squares, sum) per 64 columns) out of the first epilogue and a row scale in the second, against the three-launch form and
+    torch fp32 — in both RmsNorm forms: mean-square (timm >= 1.0.9) and unbiased variance of the un-centred row (timm <= 1.0.8 incl. the timm==1.0.3
+    upstream RDT-1B pins, models/rdt/blocks.py:22,150-156).  The stream carries a row offset (mean ~ 0.6 of the rms) so that the two forms differ."""
     from vlatouch import ops, _lib as L
     D = 2048
+    m = L.NORM_RMS_MEANSQ if mode == "meansq" else L.NORM_RMS_VAR
     a = rnd((M, D), 1, dev, dtype)
     w1 = rnd((D, D), 2, dev, dtype, D ** -0.5)
     b1 = rnd((D,), 3, dev)
-    x0 = rnd((M, D), 4, dev) * 3.0
+    x0 = rnd((M, D), 4, dev) * 3.0 + 2.0
     gain = rnd((D,), 5, dev) * 0.2 + 1.0
     w2 = rnd((N2, D), 6, dev, dtype, D ** -0.5)
     b2 = rnd((N2,), 7, dev)
     hw = (rnd((64,), 8, dev) * 0.1 + 1.0) if hn else None
     wp1, wp2 = ops.pack_w32(w1), ops.pack_w32(w2)
-    head = (hw, N2, None, N2, 1e-6, L.NORM_RMS_MEANSQ) if hn else None
+    head = (hw, N2, None, N2, 1e-6, m) if hn else None
     act = L.ACT_NONE if hn else L.ACT_GELU_TANH
     # three launches
     xa = x0.clone()
     ops.gemm(a, w1, b1, residual=xa, out=xa, out_dtype=torch.float32, wp=wp1)
-    xn_ref = ops.rownorm(xa, gain, None, eps=1e-6, mode=L.NORM_RMS_MEANSQ, out_dtype=dtype)
+    xn_ref = ops.rownorm(xa, gain, None, eps=1e-6, mode=m, out_dtype=dtype)
     y3 = ops.gemm(xn_ref, w2, b2, act=act, headnorm=head, wp=wp2)
     # hand-off
     xb = torch.cat([x0, torch.full((2, D), 7.0, device=dev)])                  # guard rows
     xo = torch.full((M + 2, D), 7.0, dtype=dtype, device=dev)
-    part = torch.full((M + 2, 2 * D // 128), 7.0, device=dev)
+    part = torch.full((M + 2, 2 * D // 128, 2), 7.0, device=dev)
     ops.gemm(a, w1, b1, residual=xb[:M], out=xb[:M], out_dtype=torch.float32, wp=wp1, xn=(xo[:M], gain, part[:M]))
     assert torch.equal(xb[:M], xa)                                             # the fp32 stream itself: the same arithmetic
     assert bool((xb[M:] == 7.0).all()) and bool((xo[M:] == 7.0).all()) and bool((part[M:] == 7.0).all())
     sq = xa.double().pow(2).view(M, -1, 64).sum(-1)
-    assert float((part[:M].double() - sq).abs().max() / sq.max()) < 1e-5
-    y2 = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6))
+    sm = xa.double().view(M, -1, 64).sum(-1)
+    assert float((part[:M, :, 0].double() - sq).abs().max() / sq.max()) < 1e-5
+    assert float((part[:M, :, 1].double() - sm).abs().max() / sm.abs().max()) < 1e-5
+    y2 = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, m))
     # torch fp32 reference from the same fp32 stream
-    xr = xa * torch.rsqrt(xa.pow(2).mean(-1, keepdim=True) + 1e-6) * gain
+    stat = xa.pow(2).mean(-1, keepdim=True) if mode == "meansq" else xa.var(-1, keepdim=True)
+    xr = xa * torch.rsqrt(stat + 1e-6) * gain
     ref = xr @ w2.float().t() + b2
     if hn:
         r = ref.view(M, -1, 64)
-        ref = (r * torch.rsqrt(r.pow(2).mean(-1, keepdim=True) + 1e-6) * hw).reshape(M, N2)
+        hstat = r.pow(2).mean(-1, keepdim=True) if mode == "meansq" else r.var(-1, keepdim=True)
+        ref = (r * torch.rsqrt(hstat + 1e-6) * hw).reshape(M, N2)
     else:
         ref = torch.nn.functional.gelu(ref, approximate="tanh")
     scale = float(ref.abs().max())
     e2, e3 = float((y2.float() - ref).abs().max()) / scale, float((y3.float() - ref).abs().max()) / scale
     tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
     assert e2 < tol and e2 < 1.5 * e3 + 1e-4, (e2, e3)                         # as close to fp32 as the three-launch form
-    y2b = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6))
+    y2b = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, m))
     assert torch.equal(y2, y2b)
+    if mode == "var":      # and the two forms really differ on this stream (a consumer that ignored rs_mode would pass the mean-square reference)
+        y_ms = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, L.NORM_RMS_MEANSQ))
+        if not hn:
+            assert float((y_ms.float() - y2.float()).abs().max()) / scale > 2e-2

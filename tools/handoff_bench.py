@@ -40,7 +40,7 @@ for N2 in (2048, 6144):
     gain = rn(D) * 0.2 + 1.0
     x = rn(M, D) * 3.0
     xo = torch.empty(M, D, dtype=torch.bfloat16, device=dev)
-    part = torch.empty(M, 2 * D // 128, device=dev)
+    part = torch.empty(M, 2 * D // 128, 2, device=dev)
     y = torch.empty(M, N2, dtype=torch.bfloat16, device=dev)
     hw = rn(64) * 0.1 + 1.0
     head = (hw, N2, None, N2, 1e-6, L.NORM_RMS_MEANSQ)

@@ -39,11 +39,13 @@ struct VtGemmParams {
   // scratch of the small-M tile of vt_gemm_pws.hip when it splits K over blocks: fp32 partial slabs [S][M][N] (sk_ws_bytes available) and
   // one zero-initialised, self-resetting ticket counter per 96 x 64 output tile (sk_cnt_n of them).  Null = that tile keeps S = 1.
   void* sk_ws; size_t sk_ws_bytes; int* sk_cnt; int sk_cnt_n;
-  // RMSNorm hand-off between a residual Linear and the Linear that consumes norm(x) * gain (vt_gemm_pw.hip only; mean-square form):
+  // RMSNorm hand-off between a residual Linear and the Linear that consumes norm(x) * gain (vt_gemm_pw.hip only):
   //   producer (fp32 C = residual + product): besides C it writes xn_out[m][n] = C[m][n] * xn_gain[n] in the 16-bit operand type (row stride xn_ld)
-  //     and xn_part[m][2 * (n / 128) + (n % 128) / 64] = the sum of squares of C over those 64 columns — no atomics, fixed order;
-  //   consumer (A = that xn_out): every accumulator row is multiplied by rstd[m] = rsqrt(rs_inv_k * sum_{j < rs_n} rs_part[m][j] + rs_eps)
-  //     before the bias — (x * gain) W^T * rstd = (x * rstd * gain) W^T, the norm launch between the two Linears disappears.
+  //     and the PAIR xn_part[m][j = 2 * (n / 128) + (n % 128) / 64][2] = (sum of squares, sum) of C over those 64 columns — no atomics, fixed order;
+  //   consumer (A = that xn_out): every accumulator row is multiplied by rstd[m] before the bias — (x * gain) W^T * rstd = (x * rstd * gain) W^T, the
+  //     norm launch between the two Linears disappears.  With Q = sum_{j < rs_n} rs_part[m][j][0], S = sum_j rs_part[m][j][1], K = 1 / rs_inv_k:
+  //       rs_mode 0 / 1 (mean-square, timm >= 1.0.9):            rstd = rsqrt(Q / K + rs_eps)
+  //       rs_mode 2 (unbiased variance, x not centred, <= 1.0.8): rstd = rsqrt((Q - S^2 / K) / (K - 1) + rs_eps)
   void* xn_out; long xn_ld; const float* xn_gain; float* xn_part;
-  const float* rs_part; int rs_n; float rs_inv_k, rs_eps;
+  const float* rs_part; int rs_n; float rs_inv_k, rs_eps; int rs_mode;
 };

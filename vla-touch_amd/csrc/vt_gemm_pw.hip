@@ -158,19 +158,23 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
   frags(af[0], 0, 0);
   if constexpr (ABL == 1) frags(af[1], 0, 1);
 
-  float4 rsv[FUSE == 2 ? 8 : 1];
+  // consumer of a fused RMSNorm: the block's 160 rows x rs_n (sum x^2, sum x) pairs = 160 * rs_n / 2 float4, dealt flat over the 256 threads
+  // (float4 q = tid + 256 i: row q / (rs_n / 2), two pairs of that row) — 10 loads per thread at rs_n = 32 instead of 16 on 160 of the threads
+  constexpr int RSV = FUSE == 2 ? (BM * 16 + 255) / 256 : 1;
+  float4 rsv[RSV];
   auto sub = [&](const int t, auto uc, auto tailc) {
     constexpr int U = decltype(uc)::value;
     constexpr bool TAIL = decltype(tailc)::value;
     if constexpr (!TAIL || U == 0) issue(t + NB - 1, std::integral_constant<int, (U + NB - 1) % NB>{});
     if constexpr (FUSE == 2 && TAIL && U == NB - 2) {
-      // consumer of a fused RMSNorm: the row's sums of squares are requested HERE — behind the last counted wait of the k-loop (the queue is empty, no
-      // later wait counts operations) and two k-tiles ahead of the epilogue that needs them, so neither the start of the k-loop nor its end waits for them
-      if (tid < BM) {
-        const float4* pp = reinterpret_cast<const float4*>(p.rs_part + (long)min(m0 + tid, p.M - 1) * p.rs_n);
-        const int n4 = p.rs_n >> 2;
+      // requested HERE — behind the last counted wait of the k-loop (the queue is empty, no later wait counts operations) and two k-tiles ahead of
+      // the epilogue that needs them, so neither the start of the k-loop nor its end waits for them
+      const int h2 = p.rs_n >> 1, nq = BM * h2;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) rsv[i] = i < n4 ? pp[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int i = 0; i < RSV; ++i) {
+        const int q = tid + 256 * i;
+        const int row = q / h2, c = q - row * h2;
+        rsv[i] = q < nq ? *reinterpret_cast<const float4*>(p.rs_part + ((long)min(m0 + row, p.M - 1) * p.rs_n + 2 * c) * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
 #pragma unroll
@@ -217,12 +221,24 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
 #pragma unroll
   for (int j = 0; j < TMW; ++j) rs[j] = 1.f;
   if constexpr (FUSE == 2) {
-    // rstd of the block's 160 rows (one row per thread, fixed summation order), handed to the lanes that own the rows' accumulators through the dead ring
-    if (tid < BM) {
-      float sq = 0.f;
+    // rstd of the block's 160 rows through the dead ring: every thread folds its float4s to (sum x^2, sum x) of two pairs, one thread per row adds the
+    // row's rs_n / 2 entries in a fixed order and hands rstd to the lanes that own the row's accumulators.
+    //   mean-square form (timm >= 1.0.9):  rstd = rsqrt(sum x^2 / K + eps)
+    //   variance form (timm <= 1.0.8, x not centred):  rstd = rsqrt((sum x^2 - (sum x)^2 / K) / (K - 1) + eps)
+    float2* pair = reinterpret_cast<float2*>(tile + BM);
+    const int h2 = p.rs_n >> 1;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sq += (rsv[i].x + rsv[i].y) + (rsv[i].z + rsv[i].w);
-      tile[tid] = rsqrtf(sq * p.rs_inv_k + p.rs_eps);
+    for (int i = 0; i < RSV; ++i) {
+      const int q = tid + 256 * i;
+      if (q < BM * h2) pair[q] = make_float2(rsv[i].x + rsv[i].z, rsv[i].y + rsv[i].w);
+    }
+    __syncthreads();
+    if (tid < BM) {
+      float sq = 0.f, sm = 0.f;
+      for (int c = 0; c < h2; ++c) { const float2 v = pair[tid * h2 + c]; sq += v.x; sm += v.y; }
+      float var = sq * p.rs_inv_k;
+      if (p.rs_mode == 2) { const float kf = 1.0f / p.rs_inv_k; var = fmaxf(sq - sm * sm * p.rs_inv_k, 0.f) / (kf - 1.0f); }
+      tile[tid] = rsqrtf(var + p.rs_eps);
     }
     __syncthreads();
 #pragma unroll
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
     }
   } else if (FUSE == 1 && PRE && use_pre) {
     // producer of a fused RMSNorm: C = residual + colscale * (product + bias) as below, plus the 16-bit copy C * gain the next Linear reads as its
-    // A operand and the sum of squares of this row over the wave's 64 columns (all 16 lanes of a row segment take part in the reduction)
+    // A operand and the (sum of squares, sum) of this row over the wave's 64 columns (all 16 lanes of a row segment take part in the reductions)
     if constexpr (PRE && FUSE == 1) {
       const float4 g4 = col_ok ? *reinterpret_cast<const float4*>(p.xn_gain + n) : zero4;
       T16* Xn = reinterpret_cast<T16*>(p.xn_out);
@@ -293,12 +309,13 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
         o[0] += rpre[it].x; o[1] += rpre[it].y; o[2] += rpre[it].z; o[3] += rpre[it].w;
         const bool ok = m < p.M && col_ok;
         const float q = row16_sum(ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f);
+        const float q1 = row16_sum(ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f);           // the variance form of the consumer also needs the row sum
         if (ok) {
           vt_epi_st128(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n, make_float4(o[0], o[1], o[2], o[3]));
           T16 ov[4] = {Elem<T16>::from_f(o[0] * g4.x), Elem<T16>::from_f(o[1] * g4.y), Elem<T16>::from_f(o[2] * g4.z), Elem<T16>::from_f(o[3] * g4.w)};
           vt_epi_st64(Xn + (long)m * p.xn_ld + n, *reinterpret_cast<const uint2*>(ov));
         }
-        if (c4 == 0 && m < p.M) p.xn_part[(long)m * pn + pcol] = q;
+        if (c4 == 0 && m < p.M) *reinterpret_cast<float2*>(p.xn_part + ((long)m * pn + pcol) * 2) = make_float2(q, q1);
       }
     }
   } else if (use_pre) {

@@ -59,6 +59,7 @@ struct vt_rdt_s {
   const float *normf, *ffc1_b, *ffc2_b;
   const void *ffc1_w, *ffc2_w;
   const void *ffc1_wp, *ffc2_wp, *t_w1p, *t_w2p;      // + the small per-step Linears (timestep embedder, final projection; state adaptor: Adaptor::wp)
+  int state_f32 = 1;            // bf16 mode: keep the solver state, the network's x0 output and the final projection in fp32 (vt_rdt_set_state_precision)
   float score_bound[64];        // per block: upper bound of |q . k| * scale in its cross-attention (vt_rdt_set_score_bounds), 0 = unknown
   Adaptor lang, img, state;
 };
@@ -104,6 +105,16 @@ void vt_rdt_destroy(vt_rdt_t h) { delete h; }
 int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n) {
   if (!h || !bounds || n != h->d.depth) return vt_fail(VT_ERR_ARG, "vt_rdt_set_score_bounds: one bound per block");
   for (int l = 0; l < n; ++l) h->score_bound[l] = bounds[l] > 0.f ? bounds[l] : 0.f;
+  return VT_OK;
+}
+
+// Precision of what the DPM-Solver++ loop carries between network evaluations in the 16-bit mode.  fp32_state = 1 (default): the final projection
+// writes fp32, the x0 predictions and the solver state stay fp32 (only the copy fed to the action-token adaptor is rounded, as any bf16 GEMM operand is) —
+// strictly closer to the fp32 reference (at RDT-1B, B = 32: |chunk - oracle| 7.7e-3 -> see DESIGN.md section 3).  fp32_state = 0: the reference's own
+// rounding points in bf16 (`noisy_action.to(dtype)` after every scheduler step, rdt_runner.py:160; bf16 model output).  No effect in fp32 mode.
+int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state) {
+  if (!h) return vt_fail(VT_ERR_ARG, "vt_rdt_set_state_precision: null handle");
+  h->state_f32 = fp32_state ? 1 : 0;
   return VT_OK;
 }
 
@@ -186,12 +197,12 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   w.kv_lang = take(w.kv_lang_blk * n_lang_blk);
   w.kv_img = take(w.kv_img_blk * n_img_blk);
   const size_t M = (size_t)B * N;
-  w.rs_part = take(M * (2 * (D / 128) + 4) * 4);      // fused RMSNorm hand-off: sums of squares per (row, 64 columns)
+  w.rs_part = take(M * (2 * (D / 128) + 4) * 8);      // fused RMSNorm hand-off: (sum of squares, sum) per (row, 64 columns)
   w.x = take(M * D * 4); w.xn = take(M * D * a); w.qkv = take(M * 3 * D * a); w.q = take(M * D * a); w.att = take(M * D * a); w.hid = take(M * D * a);
   w.sa_in = take((size_t)B * d.horizon * 2 * d.state_dim * a);
   w.sa_tmpA = take((size_t)B * d.horizon * D * a); w.sa_tmpB = take((size_t)B * d.horizon * D * a);
-  w.out_tok = take(M * d.out_dim * a);
-  w.x0_cur = take((size_t)B * d.horizon * d.out_dim * a); w.x0_prev = take((size_t)B * d.horizon * d.out_dim * a);
+  w.out_tok = take(M * d.out_dim * 4);                 // (sized for the fp32 form of vt_rdt_sample's solver loop)
+  w.x0_cur = take((size_t)B * d.horizon * d.out_dim * 4); w.x0_prev = take((size_t)B * d.horizon * d.out_dim * 4);
   w.noisy = take((size_t)B * d.horizon * d.out_dim * 4); w.noisy_a = take((size_t)B * d.horizon * d.out_dim * a);
   w.slab_bytes = M <= 512 ? (size_t)RDT_MAX_SPLITK * M * 3 * D * 4 : 0;
   w.slab = take(w.slab_bytes);
@@ -205,6 +216,7 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
 }
 
 struct RCtx { const vt_rdt_s* h; int B, L; char* ws; RWs w; hipStream_t s; int a;
+              bool out_f32 = false;       // the final projection writes out_tok in fp32 (vt_rdt_sample with the fp32 solver state)
               bool fuse_norm = false;     // residual Linears hand the RMSNorm that follows them to the next Linear (vt_gemm.h, xn_out / rs_part)
               bool rs_pending = false; }; // c.w.xn holds x * gain, un-normalised: the next Linear applies rstd from c.w.rs_part
 
@@ -390,6 +402,7 @@ int take_rstd(RCtx& c, VtGemmParams& p, const float* gain) {
   c.rs_pending = false;
   VtGemmParams q = p;
   q.rs_part = (const float*)(c.ws + c.w.rs_part); q.rs_n = 2 * (c.h->d.hidden / 128); q.rs_inv_k = 1.0f / (float)c.h->d.hidden; q.rs_eps = 1e-6f;
+  q.rs_mode = c.h->d.rms_mode;
   if (q.c_dtype != VT_F32 && vt_gemm_fast_eligible(q) && vt_gemm_pw_eligible(q)) { p = q; return VT_OK; }
   const vt_rdt_desc& d = c.h->d;
   return vt_k_rownorm((const float*)(c.ws + c.w.x), VT_F32, d.hidden, c.ws + c.w.xn, d.adt, d.hidden, gain, nullptr, p.M, d.hidden, 1e-6f, d.rms_mode, c.s);
@@ -403,7 +416,8 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
   bool xn_ready = false;              // c.w.xn already holds the next norm of x (fused into the previous residual Linear's slab reduction)
   // RMSNorm hand-off (VtGemmParams::xn_out / rs_part): when every Linear of a block runs on the weights-in-registers tile (batch 32: M = 2144) the three
   // norm launches of a block disappear — the residual Linear writes x * gain + sums of squares, the next Linear scales its rows by rstd.
-  // Mean-square form only (the variance form of timm <= 1.0.8 needs the row mean as well); VLATOUCH_RDT_FUSE_NORM=0 for A/B.
+  // Both RmsNorm forms (round 5: the producer hands over the row sums beside the sums of squares, which is what the variance form of
+  // timm <= 1.0.8 needs); VLATOUCH_RDT_FUSE_NORM=0 for A/B.
   {
     static const bool on = [] { const char* e = getenv("VLATOUCH_RDT_FUSE_NORM"); return !e || atoi(e) != 0; }();
     const Blk& b0 = c.h->blk[0];
@@ -411,7 +425,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     pr.residual = x; pr.ldr = D;
     VtGemmParams c1 = lin(c.ws + c.w.xn, d.adt, D, b0.qkv_w, d.cdt, D, b0.qkv_b, c.ws + c.w.qkv, d.adt, 3 * D, M, 3 * D, D, VT_ACT_NONE, b0.qkv_wp);
     VtGemmParams c2 = lin(c.ws + c.w.xn, d.adt, D, b0.cq_w, d.cdt, D, b0.cq_b, c.ws + c.w.q, d.adt, D, M, D, D, VT_ACT_NONE, b0.cq_wp);
-    c.fuse_norm = on && d.rms_mode == VT_NORM_RMS_MEANSQ && c.w.slab_bytes == 0 && D % 128 == 0 && 2 * (D / 128) <= 32 && vt_gemm_fast_eligible(pr) &&
+    c.fuse_norm = on && (d.rms_mode == VT_NORM_RMS_MEANSQ || d.rms_mode == VT_NORM_RMS_VAR) && c.w.slab_bytes == 0 && D % 128 == 0 && 2 * (D / 128) <= 32 && vt_gemm_fast_eligible(pr) &&
                   vt_gemm_pw_eligible(pr) && vt_gemm_fast_eligible(c1) && vt_gemm_pw_eligible(c1) && vt_gemm_fast_eligible(c2) && vt_gemm_pw_eligible(c2);
     c.rs_pending = false;
   }
@@ -462,7 +476,8 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
   if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
   { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, c.h->ffc1_w, d.cdt, D, c.h->ffc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, c.h->ffc1_wp);
     CK(rgemm(c, p, "rdt final fc1")); }
-  { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE, c.h->ffc2_wp);
+  { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, c.h->ffc2_w, d.cdt, D, c.h->ffc2_b, c.ws + c.w.out_tok, c.out_f32 ? VT_F32 : d.adt, d.out_dim, M, d.out_dim, D, VT_ACT_NONE,
+                         c.h->ffc2_wp);
     CK(rgemm(c, p, "rdt final fc2")); }
   return VT_OK;
 }
@@ -518,7 +533,7 @@ __global__ void build_sa_in_kernel(const float* __restrict__ noisy, const void* 
 }
 
 // x0 = out_tok[:, -horizon:, :]  (model.py:164) gathered contiguous
-__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_bf16) {
+__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_bf16) {      // is_bf16: both buffers 16-bit, else both fp32
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
@@ -528,21 +543,23 @@ __global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N,
   if (is_bf16) ((bf16_t*)x0)[i] = ((const bf16_t*)out_tok)[src]; else ((float*)x0)[i] = ((const float*)out_tok)[src];
 }
 
-// noisy = round_adt(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163)
+// noisy = round(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163).  x0_bf16: storage type of the x0 buffers; round_bf16:
+// the reference's `noisy_action.to(dtype)` after every step (off when the solver state is kept in fp32); mask_bf16: storage type of the action mask
 __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, const void* x0p, float a, float b0, float b1, const void* mask, int last,
-                                  int B, int Hh, int S, int is_bf16, int sample_pred, float alpha_s, float sigma_s, void* x0_store, float* __restrict__ out) {
+                                  int B, int Hh, int S, int x0_bf16, int round_bf16, int mask_bf16, int sample_pred, float alpha_s, float sigma_s, void* x0_store,
+                                  float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
   const int b = (int)(i / ((long)Hh * S));
-  float m0 = is_bf16 ? bf2f(((const bf16_t*)x0)[i]) : ((const float*)x0)[i];
+  float m0 = x0_bf16 ? bf2f(((const bf16_t*)x0)[i]) : ((const float*)x0)[i];
   if (!sample_pred) m0 = (noisy[i] - sigma_s * m0) / alpha_s;          // epsilon prediction -> x0
-  if (x0_store) { if (is_bf16) ((bf16_t*)x0_store)[i] = f2bf(m0); else ((float*)x0_store)[i] = m0; }
+  if (x0_store) { if (x0_bf16) ((bf16_t*)x0_store)[i] = f2bf(m0); else ((float*)x0_store)[i] = m0; }
   float v = a * noisy[i] + b0 * m0;
-  if (x0p) v += b1 * (is_bf16 ? bf2f(((const bf16_t*)x0p)[i]) : ((const float*)x0p)[i]);
-  if (is_bf16) v = bf2f(f2bf(v));                                   // `noisy_action.to(state_traj.dtype)` (rdt_runner.py:160)
-  if (last) v *= is_bf16 ? bf2f(((const bf16_t*)mask)[(long)b * S + c]) : ((const float*)mask)[(long)b * S + c];
-  if (last && is_bf16) v = bf2f(f2bf(v));
+  if (x0p) v += b1 * (x0_bf16 ? bf2f(((const bf16_t*)x0p)[i]) : ((const float*)x0p)[i]);
+  if (round_bf16) v = bf2f(f2bf(v));                                // `noisy_action.to(state_traj.dtype)` (rdt_runner.py:160)
+  if (last) v *= mask_bf16 ? bf2f(((const bf16_t*)mask)[(long)b * S + c]) : ((const float*)mask)[(long)b * S + c];
+  if (last && round_bf16) v = bf2f(f2bf(v));
   noisy[i] = v;
   if (out) out[i] = v;                                              // the last step also writes the caller's buffer
 }
@@ -621,6 +638,10 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
   CK(vt_check_launch());
   char* x0_cur = c.ws + c.w.x0_cur;
   char* x0_prev = c.ws + c.w.x0_prev;
+  // 16-bit mode with the fp32 solver state (the default, vt_rdt_set_state_precision): fp32 final projection / x0 buffers, no per-step rounding of the state
+  const int st32 = bf && h->state_f32;
+  const int x0_bf = bf && !st32;
+  c.out_f32 = st32;
   for (int k = 0; k < n_steps; ++k) {
     hipLaunchKernelGGL(build_sa_in_kernel, g1((long)B * Hh * 2 * S), dim3(256), 0, s, (const float*)(c.ws + c.w.noisy), action_mask, (void*)(c.ws + c.w.sa_in), B, Hh, S, bf);
     CK(vt_check_launch());
@@ -631,12 +652,12 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
                        h->x_pos, B, N, D, bf);
     CK(vt_check_launch());
     CK(run_blocks(c, lang_mask));
-    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, bf);
+    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, x0_bf);
     CK(vt_check_launch());
     const float* cf = coef + 5 * k;
     const bool last = k == n_steps - 1;
     hipLaunchKernelGGL(dpm_update_kernel, g1(n), dim3(256), 0, s, (float*)(c.ws + c.w.noisy), (const void*)x0_cur, (const void*)(cf[2] != 0.f ? x0_prev : nullptr), cf[0], cf[1],
-                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, bf, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
+                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, x0_bf, x0_bf, bf, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
     CK(vt_check_launch());
     char* t = x0_cur; x0_cur = x0_prev; x0_prev = t;
   }

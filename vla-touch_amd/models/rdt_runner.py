@@ -72,8 +72,10 @@ def resolve_rms_mode(explicit: Optional[str], rdt_cfg: dict) -> str:
 class RDTRunner:
     def __init__(self, *, action_dim, pred_horizon, config, lang_token_dim, img_token_dim, state_token_dim, max_lang_cond_len,
                  img_cond_len, lang_pos_embed_config=None, img_pos_embed_config=None, dtype=torch.bfloat16, device="cuda",
-                 rms_mode: Optional[str] = None, init_weights: bool = True):
+                 rms_mode: Optional[str] = None, init_weights: bool = True, solver_state: Optional[str] = None):
         hidden_size = config['rdt']['hidden_size']
+        # precision of the sampler's state between network evaluations in the 16-bit mode (extension; RdtEngine): "fp32" (default) or the reference's "bf16"
+        self.solver_state = solver_state or config.get('rdt', {}).get('solver_state') or os.environ.get("VLATOUCH_RDT_SOLVER_STATE", "fp32")
         self.config = config
         self.dtype = dtype
         self.device = device
@@ -162,7 +164,7 @@ class RDTRunner:
                 horizon=self.pred_horizon, action_dim=self.action_dim, lang_token_dim=self.lang_token_dim, img_token_dim=self.img_token_dim,
                 state_token_dim=self.state_token_dim, max_lang_cond_len=self.max_lang_cond_len, img_cond_len=self.img_cond_len,
                 lang_adaptor=self.config['lang_adaptor'], img_adaptor=self.config['img_adaptor'], state_adaptor=self.config['state_adaptor'],
-                dtype=self.dtype, rms_mode=self.rms_mode, device=self.device)
+                dtype=self.dtype, rms_mode=self.rms_mode, solver_state=self.solver_state, device=self.device)
             self._engine_key = key
         return self._engine
 
@@ -204,7 +206,7 @@ class RDTRunner:
     def predict_action(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init=None, return_fp32=False):
         """lang_tokens (B, L, lang_dim), lang_attn_mask (B, L) bool, img_tokens (B, img_len, img_dim), state_tokens (B, 1, state_dim),
         action_mask (B, 1, action_dim) 0/1 float, ctrl_freqs (B,) -> (B, horizon, action_dim)  (rdt_runner.py:225-250).
-        return_fp32 (not in the reference): hand back the engine's fp32 buffer (values on the dtype's grid) instead of casting it."""
+        return_fp32 (not in the reference): hand back the fp32 buffer of the solver (un-rounded with solver_state="fp32", on the dtype grid with "bf16") instead of casting it to dtype."""
         eng = self.engine()
         B = lang_tokens.shape[0]
         if x_init is None:

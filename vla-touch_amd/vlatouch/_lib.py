@@ -45,7 +45,7 @@ class GemmParams(C.Structure):
         ("sk_ws", C.c_void_p), ("sk_ws_bytes", C.c_size_t), ("sk_cnt", C.c_void_p), ("sk_cnt_n", C.c_int),
         # fused RMSNorm hand-off between two Linears (vt_gemm.h): producer side / consumer side
         ("xn_out", C.c_void_p), ("xn_ld", C.c_long), ("xn_gain", C.c_void_p), ("xn_part", C.c_void_p),
-        ("rs_part", C.c_void_p), ("rs_n", C.c_int), ("rs_inv_k", C.c_float), ("rs_eps", C.c_float),
+        ("rs_part", C.c_void_p), ("rs_n", C.c_int), ("rs_inv_k", C.c_float), ("rs_eps", C.c_float), ("rs_mode", C.c_int),
     ]
 
 
@@ -164,6 +164,7 @@ SIGNATURES = {
     "vt_rdt_num_weights": (_I, [_P]),
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_rdt_set_score_bounds": (_I, [_P, _P, _I]),
+    "vt_rdt_set_state_precision": (_I, [_P, _I]),
     "vt_rdt_packed_bytes": (_Z, [_P]),
     "vt_rdt_set_packed": (_I, [_P, _P, _P]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),

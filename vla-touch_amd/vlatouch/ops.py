@@ -22,8 +22,9 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     """out[M,N] = residual + colscale * act(a[M,K] @ w[N,K]^T + bias).  splitk>1 returns the fp32 slabs [splitk,M,N].
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
     cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout.
-    RMSNorm hand-off between two Linears on the weights-in-registers tile (csrc/vt_gemm.h): xn = (xn_out [M, N] 16-bit, gain [N] fp32, part [M, 2N/128] fp32) on the
-    residual Linear (fp32 out), rs = (part, eps) on the Linear that reads xn_out as `a`."""
+    RMSNorm hand-off between two Linears on the weights-in-registers tile (csrc/vt_gemm.h): xn = (xn_out [M, N] 16-bit, gain [N] fp32, part [M, 2N/128, 2] fp32:
+    (sum of squares, sum) per 64 columns) on the residual Linear (fp32 out), rs = (part, eps[, mode = NORM_RMS_MEANSQ | NORM_RMS_VAR]) on the Linear that reads
+    xn_out as `a`."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     M, K = a.shape
     N = w.shape[0]
@@ -57,12 +58,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         p.sk_ws, p.sk_ws_bytes, p.sk_cnt, p.sk_cnt_n = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size(), sk_cnt.data_ptr(), sk_cnt.numel()
     if xn is not None:
         xo, gain, part = xn
-        assert xo.shape == (M, N) and xo.dtype == a.dtype and gain.dtype == torch.float32 and part.dtype == torch.float32 and part.shape == (M, 2 * N // 128)
+        assert xo.shape == (M, N) and xo.dtype == a.dtype and gain.dtype == torch.float32 and part.dtype == torch.float32 and part.shape == (M, 2 * N // 128, 2) and part.is_contiguous()
         p.xn_out, p.xn_ld, p.xn_gain, p.xn_part = xo.data_ptr(), xo.stride(0), gain.data_ptr(), part.data_ptr()
     if rs is not None:
-        part, eps = rs
-        assert part.dtype == torch.float32 and part.shape[0] == M and part.is_contiguous()
+        part, eps = rs[0], rs[1]
+        assert part.dtype == torch.float32 and part.shape[0] == M and part.dim() == 3 and part.shape[2] == 2 and part.is_contiguous()
         p.rs_part, p.rs_n, p.rs_inv_k, p.rs_eps = part.data_ptr(), part.shape[1], 1.0 / K, eps
+        p.rs_mode = rs[2] if len(rs) > 2 else L.NORM_RMS_MEANSQ
     L.check(L.lib().vt_gemm(C.byref(p), L.stream_ptr(a.device)), "vt_gemm")
     return out
 

@@ -29,8 +29,13 @@ class RdtEngine:
     def __init__(self, sd: SD, *, hidden: int, depth: int, heads: int, horizon: int, action_dim: int, lang_token_dim: int,
                  img_token_dim: int, state_token_dim: int, max_lang_cond_len: int, img_cond_len: int,
                  lang_adaptor: str = "mlp2x_gelu", img_adaptor: str = "mlp2x_gelu", state_adaptor: str = "mlp3x_gelu",
-                 dtype: torch.dtype = torch.bfloat16, rms_mode: str = "meansq", device="cuda"):
+                 dtype: torch.dtype = torch.bfloat16, rms_mode: str = "meansq", solver_state: str = "fp32", device="cuda"):
+        """solver_state (16-bit mode only): "fp32" (default) keeps the DPM-Solver++ state, the x0 predictions and the final projection in fp32 between
+        network evaluations — closer to the fp32 reference; "bf16" reproduces the reference's bf16 rounding points (rdt_runner.py:137-139,160)."""
         self.device = L.require_gpu(device)
+        if solver_state not in ("fp32", "bf16"):
+            raise ValueError(f"solver_state must be 'fp32' or 'bf16', got {solver_state!r}")
+        self.solver_state = solver_state
         if hidden // heads != 64:
             raise L.VtError("RdtEngine: head_dim must be 64")
         self.dtype = dtype
@@ -77,6 +82,7 @@ class RdtEngine:
         assert lib.vt_rdt_num_weights(C.byref(d)) == len(W), (lib.vt_rdt_num_weights(C.byref(d)), len(W))
         self._h = C.c_void_p()
         L.check(lib.vt_rdt_create(C.byref(d), L.ptr_array(W), len(W), C.byref(self._h)), "vt_rdt_create")
+        L.check(lib.vt_rdt_set_state_precision(self._h, int(solver_state == "fp32")), "vt_rdt_set_state_precision")
         self._ws = _Workspace(dev)
         # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
         self._depth, self._rms_mode = depth, rms_mode
