@@ -56,7 +56,9 @@ int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t st
  *          tools/gemm_bench_pw.py --abl; the shipped library rejects any value but 0);
  * knob 6 = fixed-maximum softmax of the cached cross-attention on (1) / off (0: always the online form);
  * knob 7 = fused U-Net sampler path (vt_unet_fused_pack) on (1) / off (0: the launch-per-op driver);
- * knob 8 = persistent 256-square GEMM tile with the in-loop epilogue (csrc/vt_gemm_pt.hip) on (1) / off (0: gemm_pp256d_kernel). */
+ * knob 8 = persistent 256-square GEMM tile with the in-loop epilogue (csrc/vt_gemm_pt.hip) on (1) / off (0: gemm_pp256d_kernel);
+ * knob 9 = grouped-query ViT self-attention (csrc/vt_attn.hip, attn16g_kernel: a block walks the keys once for G x 16 query rows per wave):
+ *          0 off (attn16u_kernel), 1 on with G chosen per shape (default), 3 / 6 = G pinned. */
 int vt_tune(int knob, int value);
 
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.

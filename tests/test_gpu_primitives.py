@@ -276,6 +276,36 @@ def test_attention_head_dim_80(dev, mode, Nq, Nk):
         ops.attention(q.float(), k.float(), v.float(), scale=72 ** -0.5)          # fp32 keeps 96-wide padding
 
 
+@pytest.mark.parametrize("mode", ["bf16", "f16"])
+@pytest.mark.parametrize("N,hd,B,H", [(729, 80, 3, 4), (257, 64, 5, 3), (730, 64, 2, 3), (1370, 64, 1, 6), (128, 64, 2, 2), (200, 80, 2, 2)])
+def test_grouped_query_attention_is_bit_identical_to_one_group_per_wave(dev, mode, N, hd, B, H):
+    """attn16g_kernel (a block walks the key tiles ONCE for G groups of 16 query rows per wave: one block per (image, head) for SigLIP's 729 and
+    DINOv2's 257 tokens) against attn16u_kernel (one group per wave, six / three blocks per (image, head)): per query row the two kernels do the same
+    operations in the same order, so the outputs must be BIT-identical — for G chosen by the launcher and for G pinned to 3 and 6 (partly filled
+    last blocks, groups of padding rows skipped, a ragged last key tile) — and equal to a torch fp32 reference within the 16-bit tolerance."""
+    from vlatouch import ops, _lib as L
+    lib = L.lib()
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[mode]
+    real = 72 if hd == 80 else hd
+    qkv = rnd((B, N, 3, H, hd), 11, dev, dt)
+    if hd == 80:
+        qkv[..., 72:] = 0
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    outs = {}
+    try:
+        for knob in (0, 1, 3, 6):
+            L.check(lib.vt_tune(9, knob), "tune")
+            outs[knob] = ops.attention(q, k, v, scale=real ** -0.5)
+            torch.cuda.synchronize()
+    finally:
+        lib.vt_tune(9, 1)
+    for knob in (1, 3, 6):
+        assert torch.equal(outs[knob], outs[0]), (knob, float((outs[knob].float() - outs[0].float()).abs().max()))
+    s = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float()) * real ** -0.5
+    ref = torch.einsum("bhqk,bkhd->bqhd", torch.softmax(s, -1), v.float()).reshape(B, N, H * hd)
+    assert rel_err(outs[1].float(), ref) < {"bf16": 1.5e-2, "f16": 2e-3}[mode]
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(70, 100, 64, 1), (33, 64, 96, 1), (200, 260, 1056, 1), (512, 512, 2560, 3), (64, 1280, 2048, 8), (257, 36, 160, 2)])
 def test_fp32_ring_gemm_edges(dev, M, N, K, splitk):
     """vt_gemm_f32r.hip (bias-only exact-fp32 products with few blocks per CU): ragged M / N (clamped rows, scalar stores when N % 4 != 0),

@@ -707,6 +707,266 @@ __global__ __launch_bounds__(512) void attn16u_kernel(const VtAttnParams p) {
 #endif
 }
 
+
+// ---- attn16g_kernel (round 5): the ViT self-attention loop nest turned inside out.  attn16u_kernel gives a block 16 query rows per wave and walks the
+// whole key sequence for them: a SigLIP (image, head) is 6 blocks, each staging the same 233 KB of K / V (tools/attn_abl.sh: a third of the launch is
+// re-staging, another third the per-block fixed cost — dispatch, Q loads, first DMA round trip, 12 barriers, O stores).  Here a wave owns G query
+// groups of 16 rows (G sets of Q fragments, running (m, l) and O accumulators in registers) and a block walks the key tiles ONCE for all of its
+// 16 * nw * G rows: one block per (image, head) for SigLIP (8 waves x 6 groups = 768 >= 729 rows) and DINOv2 @224 (6 x 3 = 288 >= 257).  Inside a
+// key tile the G groups are independent instruction streams of one wave: the scheduler runs the Q K^T MFMAs of group i + 1 under the softmax VALU
+// work of group i.  Same tile image, DMA plan, fragment conventions and arithmetic (per row: identical operations in identical order) as
+// attn16u_kernel, so results are bit-identical to it.  Group gi of wave w = rows (gi * nw + w) * 16 .. + 15 of the block; groups that start past Nq
+// are skipped (wave-uniform branch).  The ring slot is a run-time value here (8 address adds per tile, amortised over G groups).
+template <int N, typename F> __device__ __forceinline__ void ag_for(F&& f) {
+  if constexpr (N > 0) { ag_for<N - 1>(f); f(IC<N - 1>{}); }
+}
+
+template <typename T, int HD, int G>
+__global__ __launch_bounds__(512) void attn16g_kernel(const VtAttnParams p) {
+  static_assert(sizeof(T) == 2, "16-bit types only");
+  constexpr int KT = 64;
+  constexpr int NKS = HD / 32, NDT = HD / 16;
+  constexpr bool TAIL16 = (HD % 32) == 16;
+  constexpr int TW = (HD - 64) * 2;
+  constexpr int MAINB = KT * 128;
+  constexpr int TILE = MAINB + KT * TW;
+  constexpr int STAGE = 2 * TILE;
+  constexpr int NST = 3;
+  constexpr int TP = KT * TW / 1024;
+  constexpr int PT = 8 + TP;
+  constexpr int PIECES = 2 * PT;
+  constexpr int MAXP = (PIECES + 3) / 4;
+  constexpr int CPR = TW > 0 ? TW / 16 : 1;
+  __shared__ __attribute__((aligned(16))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nw = blockDim.x >> 6;
+  const int g = lane >> 4, l15 = lane & 15;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int row_base = blockIdx.x * (nw * 16 * G) + wave * 16;         // + gi * nw * 16 = first row of this wave's group gi
+  const T* Q = reinterpret_cast<const T*>(p.Q) + (long)b * p.q_bs + (long)h * p.q_hs;
+  const T* K = reinterpret_cast<const T*>(p.K) + (long)b * p.k_bs + (long)h * p.k_hs;
+  const T* V = reinterpret_cast<const T*>(p.V) + (long)b * p.v_bs + (long)h * p.v_hs;
+  const int ntiles = (p.Nk + KT - 1) / KT;
+
+  const int my_pieces = (PIECES - wave + nw - 1) / nw;
+  unsigned poff[MAXP];
+#pragma unroll
+  for (int n = 0; n < MAXP; ++n) {
+    const int i = wave + n * nw;
+    const bool isv = i >= PT;
+    const int j = isv ? i - PT : i;
+    const unsigned rs = (unsigned)(isv ? p.v_rs : p.k_rs);
+    if (TP == 0 || j < 8) {
+      const int r = j * 8 + (lane >> 3);
+      poff[n] = (unsigned)r * rs + (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 8);
+    } else {
+      const int r = (j - 8) * (64 / CPR) + lane / CPR;
+      poff[n] = (unsigned)r * rs + 64u + (unsigned)((lane % CPR) * 8);
+    }
+  }
+  auto piece_dst = [&](const int slot, const int i) __attribute__((always_inline)) -> char* {
+    const bool isv = i >= PT;
+    const int j = isv ? i - PT : i;
+    return smem + slot * STAGE + (isv ? TILE : 0) + ((TP == 0 || j < 8) ? j * 1024 : MAINB + (j - 8) * 1024);
+  };
+  auto stage = [&](const int slot, const int tile) __attribute__((always_inline)) {
+    const int key0 = tile * KT;
+    if (key0 + KT <= p.Nk) {
+      const T* kb = K + (long)key0 * p.k_rs;
+      const T* vb = V + (long)key0 * p.v_rs;
+#pragma unroll
+      for (int n = 0; n < MAXP; ++n) {
+        const int i = wave + n * nw;
+        if (i < PIECES)
+          __builtin_amdgcn_global_load_lds((glb_void_a*)((i >= PT ? vb : kb) + poff[n]), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+      }
+    } else {
+      for (int i = wave; i < PIECES; i += nw) {
+        const bool isv = i >= PT;
+        const int j = isv ? i - PT : i;
+        const T* base = isv ? V : K;
+        const long rs = isv ? p.v_rs : p.k_rs;
+        if (TP == 0 || j < 8) {
+          const int r = j * 8 + (lane >> 3);
+          const int c = (lane & 7) ^ ((r >> 1) & 7);
+          __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+        } else {
+          const int r = (j - 8) * (64 / CPR) + lane / CPR;
+          const int c = lane % CPR;
+          __builtin_amdgcn_global_load_lds((glb_void_a*)(base + (long)min(key0 + r, p.Nk - 1) * rs + 64 + c * 8), (lds_void_a*)piece_dst(slot, i), 16, 0, 0);
+        }
+      }
+    }
+  };
+  auto wait_own = [&](const bool younger_in_flight) __attribute__((always_inline)) {
+    if (!younger_in_flight) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_pieces == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else if (my_pieces == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (my_pieces == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else if (my_pieces == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (my_pieces == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else if (my_pieces == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  stage(0, 0);
+  if (ntiles > 1) stage(1, 1);
+  Frag<T> qf[G][NKS];
+  short4_t q16[G];
+  ag_for<G>([&](auto gc) {
+    constexpr int gi = decltype(gc)::value;
+    const int q = row_base + gi * nw * 16 + l15;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) QLoad<T>::ld(qf[gi][ks], Q + (long)q * p.q_rs + ks * 32 + g * 8, q < p.Nq);
+    q16[gi] = (short4_t){0, 0, 0, 0};
+    if constexpr (TAIL16) { if (q < p.Nq) q16[gi] = *reinterpret_cast<const short4_t*>(Q + (long)q * p.q_rs + NKS * 32 + g * 4); }
+  });
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int gi = 0; gi < G; ++gi) {
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(qf[gi][ks].v));
+    asm volatile("" : "+v"(q16[gi]));
+  }
+
+  const int ksw = (l15 >> 1) & 7;
+  unsigned koff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) koff[ks] = (unsigned)(l15 * 128 + (((ks * 4 + g) ^ ksw) * 16));
+  const unsigned ktail = (unsigned)(MAINB + l15 * TW + g * 16);
+  const unsigned ktail16 = (unsigned)(MAINB + l15 * TW + (NKS - 2) * 64 + g * 8);
+  const int vkey = g * 4 + (l15 >> 2);
+  const int vsw = ((vkey >> 1) & 7) ^ ((l15 & 3) >> 1);
+  unsigned voff[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) voff[dt] = (unsigned)(TILE + vkey * 128 + (((dt * 2) ^ vsw) * 16) + (l15 & 1) * 8);
+  const unsigned vtail = (unsigned)(TILE + MAINB + vkey * TW + (l15 & 3) * 8);
+
+  float4_t o[G][NDT];
+  float m_run[G], l_run[G];
+  ag_for<G>([&](auto gc) {
+    constexpr int gi = decltype(gc)::value;
+#pragma unroll
+    for (int i = 0; i < NDT; ++i) o[gi][i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    m_run[gi] = -INFINITY; l_run[gi] = 0.f;
+  });
+  const float cscale = p.scale * 1.4426950408889634f;
+
+  int slot = 0;
+  for (int tile = 0; tile < ntiles; ++tile) {
+    const int key0 = tile * KT;
+    wait_own(tile + 1 < ntiles);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (tile + 2 < ntiles) stage(slot == 0 ? 2 : slot - 1, tile + 2);
+    // this tile's LDS addresses: slot base + the per-lane offsets computed once
+    const char* S0 = smem + slot * STAGE;
+    const char* ka0 = S0 + koff[0];
+    const char* ka1 = S0 + koff[1];
+    const char* kt_ = S0 + ktail;
+    const char* kt16 = S0 + ktail16;
+    const char* va[4] = {S0 + voff[0], S0 + voff[1], S0 + voff[2], S0 + voff[3]};
+    const char* vt_ = S0 + vtail;
+    slot = slot == NST - 1 ? 0 : slot + 1;
+    const bool ragged = key0 + KT > p.Nk;
+
+    ag_for<G>([&](auto gc) {
+      constexpr int gi = decltype(gc)::value;
+      if (row_base + gi * nw * 16 >= p.Nq) return;                      // a group of padding rows only (wave-uniform)
+      float4_t sacc[4], tacc[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+        sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        tacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          Frag<T> kf;
+          if (ks == 0) kf.v = *reinterpret_cast<const short8_t*>(ka0 + kt * 2048);
+          else if (ks == 1) kf.v = *reinterpret_cast<const short8_t*>(ka1 + kt * 2048);
+          else kf.v = *reinterpret_cast<const short8_t*>(kt_ + kt * 16 * TW + (ks - 2) * 64);
+          mma16(sacc[kt], kf, qf[gi][ks]);
+        }
+        if constexpr (TAIL16) {      // own accumulator (the SrcC hazard between the 8-pass and 4-pass MFMAs, see attn16_kernel)
+          const short4_t k16 = *reinterpret_cast<const short4_t*>(kt16 + kt * 16 * TW);
+          mma16_k16<T>(tacc[kt], k16, q16[gi]);
+        }
+      }
+      float sv[16];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sv[kt * 4 + r] = TAIL16 ? sacc[kt][r] + tacc[kt][r] : sacc[kt][r];
+      if (ragged) {
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (key0 + kt * 16 + g * 4 + r >= p.Nk) sv[kt * 4 + r] = -INFINITY;
+      }
+      float mx = sv[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[gi], mx);
+      if (__any(m_new != m_run[gi])) {
+        const float alpha = (m_run[gi] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run[gi] - m_new) * cscale);
+        l_run[gi] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[gi][dt][r] *= alpha;
+        m_run[gi] = m_new;
+      }
+      const float mc = (m_run[gi] == -INFINITY) ? 0.f : m_run[gi] * cscale;
+      float psum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
+      l_run[gi] += psum;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        float pj[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pj[j] = sv[(kb * 2 + (j >> 2)) * 4 + (j & 3)];
+        Frag<T> pf;
+        PackP<T>::pack(pf, pj);
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          Frag<T> vf;
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            const char* a = dt < 4 ? va[dt < 4 ? dt : 0] + (kb * 32 + hh * 16) * 128
+                                   : vt_ + (kb * 32 + hh * 16) * TW + (dt - 4) * 32;
+            const short4_t t = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4_t*)a);
+            vf.v[hh * 4 + 0] = t[0]; vf.v[hh * 4 + 1] = t[1]; vf.v[hh * 4 + 2] = t[2]; vf.v[hh * 4 + 3] = t[3];
+          }
+          mma16(o[gi][dt], vf, pf);
+        }
+      }
+    });
+  }
+
+  ag_for<G>([&](auto gc) {
+    constexpr int gi = decltype(gc)::value;
+    const int q = row_base + gi * nw * 16 + l15;
+    float l = l_run[gi];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    if (q < p.Nq) {
+      T* O = reinterpret_cast<T*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        T ov[4] = {Elem<T>::from_f(o[gi][dt][0] * inv), Elem<T>::from_f(o[gi][dt][1] * inv), Elem<T>::from_f(o[gi][dt][2] * inv), Elem<T>::from_f(o[gi][dt][3] * inv)};
+        *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = *reinterpret_cast<const uint2*>(ov);
+      }
+    }
+  });
+}
+
 }  // namespace
 
 #ifdef VLATOUCH_BENCH_BUILD
@@ -714,6 +974,9 @@ extern "C" int vt_attn_set_timing(long long* buf) {      // bench build only: de
   return hipMemcpyToSymbol(HIP_SYMBOL(d_attn_tbuf), &buf, sizeof(buf)) == hipSuccess ? VT_OK : VT_ERR_LAUNCH;
 }
 #endif
+
+static int g_vt_attn16g = -1;     // -1 = read VLATOUCH_ATTN16G at the first launch; 0 = attn16u_kernel everywhere, 1 = grouped-query kernel with G chosen per shape, 3 / 6 = pinned
+void vt_attn16g_tune(int value) { g_vt_attn16g = value; }
 
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0) return VT_ERR_ARG;
@@ -733,6 +996,30 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.hd != 0 && p.hd != 64 && p.hd != 96 && p.hd != 80) return VT_ERR_UNSUPPORTED;
   // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
   static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 2; }();
+  // ViT-sized query counts (>= 128 rows: DINOv2 257 / 730 / 1370 tokens, SigLIP 729): the grouped-query kernel, whole (image, head) sequences per
+  // block where they fit (attn16g_kernel; VLATOUCH_ATTN16G=0 for A/B, =3 / =6 pins the groups per wave)
+  if (g_vt_attn16g < 0) { const char* e = getenv("VLATOUCH_ATTN16G"); g_vt_attn16g = e ? atoi(e) : 1; }
+  const int a16g = g_vt_attn16g;
+  if (a16 && a16g && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nq >= 128 && (p.hd == 0 || p.hd == 64 || p.hd == 80)) {
+    // fewest blocks per (image, head), then fewest 16-row groups in them, then more waves (shorter chains per wave); G in {3, 6}
+    const int need = (p.Nq + 15) / 16;
+    int bG = 0, bW = 0; long bcost = 1L << 60;
+    for (int G : {3, 6}) {
+      if (a16g == 3 || a16g == 6) { if (G != a16g) continue; }
+      for (int w = 4; w <= 8; ++w) {
+        const int per = G * w, blocks = (need + per - 1) / per;
+        const long cost = ((long)blocks << 40) + ((long)(blocks * per - need) << 20) + (8 - w) * 64 + G;
+        if (cost < bcost) { bcost = cost; bG = G; bW = w; }
+      }
+    }
+    dim3 gg((need + bG * bW - 1) / (bG * bW), p.H, p.B);
+#define VT_A16G(T, HDv) do { if (bG == 6) hipLaunchKernelGGL((attn16g_kernel<T, HDv, 6>), gg, dim3(64 * bW), 0, s, p); \
+                             else hipLaunchKernelGGL((attn16g_kernel<T, HDv, 3>), gg, dim3(64 * bW), 0, s, p); } while (0)
+    if (p.hd == 80) { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 80); else VT_A16G(half_t, 80); }
+    else { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 64); else VT_A16G(half_t, 64); }
+#undef VT_A16G
+    return vt_check_launch();
+  }
   if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
 #define VT_A16(KERN, T) do { if (p.hd == 96) hipLaunchKernelGGL((KERN<T, 96>), grid, dim3(64 * nw), 0, s, p); \
                        else if (p.hd == 80) hipLaunchKernelGGL((KERN<T, 80>), grid, dim3(64 * nw), 0, s, p); \

@@ -208,7 +208,12 @@ __device__ __forceinline__ void pt_body(const VtGemmParams& p, char* smem, const
     }
   const float* bias = p.bias;
   auto set_stage_ctx = [&](const TileId t) __attribute__((always_inline)) {
+#ifdef VLATOUCH_BENCH_BUILD      // timing only (VLATOUCH_PT_ABL & 128, garbage results): every tile stages the A rows of m-tile (tm & 1) — the A panel becomes
+    // L2-resident (2 MB per XCD), the fabric reads of the launch drop to the W stream: does the time follow the traffic?
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (long)((abl & 128) ? (t.m0 & BM) : t.m0) * p.lda;
+#else
     const uint16_t* A = reinterpret_cast<const uint16_t*>(p.A) + (long)t.m0 * p.lda;
+#endif
     const uint16_t* W = reinterpret_cast<const uint16_t*>(p.W) + (long)t.n0 * p.ldw;
     rsA = __builtin_amdgcn_make_buffer_rsrc((void*)A, 0, 0x7fffffff, 0x00020000);
     rsW = __builtin_amdgcn_make_buffer_rsrc((void*)W, 0, 0x7fffffff, 0x00020000);

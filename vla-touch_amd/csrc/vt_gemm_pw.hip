@@ -423,6 +423,7 @@ extern "C" int vt_tune(int knob, int value) {
   if (knob == 6) { vt_attn_kvt_tune(value); return VT_OK; }
   if (knob == 7) { vt_unet_fused_tune(value); return VT_OK; }
   if (knob == 8) { vt_gemm_pt_tune(value); return VT_OK; }
+  if (knob == 9 && (value == 0 || value == 1 || value == 3 || value == 6)) { vt_attn16g_tune(value); return VT_OK; }
   if (knob == 3 || knob == 4) { vt_gemm_pws_tune(knob, value); return VT_OK; }
   return vt_fail(VT_ERR_ARG, "vt_tune: unknown knob %d / value %d", knob, value);
 }

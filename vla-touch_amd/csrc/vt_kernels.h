@@ -50,6 +50,7 @@ inline size_t vt_attn_kvt_part_bytes(int B, int H, int Nq, int parts) { return p
 __host__ __device__ inline int vt_kpos(int kk) { return (kk & 32) | (((kk >> 2) & 3) << 3) | (((kk >> 4) & 1) << 2) | (kk & 3); }
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s);
 void vt_attn_kvt_tune(int value);
+void vt_attn16g_tune(int value);      // vt_tune(9, v): grouped-query ViT self-attention (vt_attn.hip): 0 off, 1 auto, 3 / 6 = groups per wave
 // row-major K / V projections [M][ld] -> the tile stream (either source may be null)
 int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int M, int T, int H, hipStream_t s);
 
