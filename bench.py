@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--rms-mode", default="meansq", choices=["meansq", "var"],
                     help="timm RmsNorm arithmetic of RDT: meansq = timm >= 1.0.9; var = timm <= 1.0.8 incl. the timm==1.0.3 upstream RDT-1B pins (what its "
                          "released checkpoints need): no score bound exists there, so the cached cross-attention runs its ONLINE softmax")
+    ap.add_argument("--rdt-compute", default="f16", choices=["f16", "bf16"],
+                    help="16-bit activation / MFMA operand type of the bf16 RDT-1B: f16 = IEEE fp16 (default: the bf16 weights convert exactly, same width and "
+                         "MFMA rate, |chunk - fp32 oracle| 8x smaller), bf16 = the reference's own execution dtype")
     ap.add_argument("--lang-len", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--streams", type=int, default=0,
@@ -181,7 +184,7 @@ def main():
                "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": args.rdt_steps, "beta_schedule": "squaredcos_cap_v2",
                                    "prediction_type": "sample", "clip_sample": False}}
         rdt = RDTRunner(action_dim=128, pred_horizon=64, config=cfg, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128,
-                        max_lang_cond_len=1024, img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False)
+                        max_lang_cond_len=1024, img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False, compute_dtype=args.rdt_compute)
         rdt.load_state_dict(synth.fill_state_dict_device(synth.rdt_runner_shapes(**RDT1B), dev, rdt_dtype, seed=7), assign=True)
         eng = rdt.engine()
         if use_dist:
@@ -193,8 +196,10 @@ def main():
             bcast_s += time.time() - tb
             eng.repack()                                                 # the fragment-packed copies follow the received weights
         g = torch.Generator(device=dev).manual_seed(4321 + rank)
-        rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32).to(rdt_dtype)
-        amask = torch.zeros(B, 1, 128, device=dev, dtype=rdt_dtype)
+        # condition tokens are handed over in the engine's activation type (what an upstream encoder on this device writes: no cast inside the step)
+        in_dtype = rdt.compute_dtype
+        rn = lambda *s: torch.randn(*s, generator=g, device=dev, dtype=torch.float32).to(in_dtype)
+        amask = torch.zeros(B, 1, 128, device=dev, dtype=in_dtype)
         amask[:, :, :10] = 1.0                                       # the 10 EEF dims of the unified action vector
         mk_rin = lambda: dict(lang=rn(B, args.lang_len, 4096), mask=torch.ones(B, args.lang_len, dtype=torch.bool, device=dev), img=rn(B, 4374, 1152),
                               state=rn(B, 1, 128), amask=amask, freq=torch.full((B,), 10.0, device=dev))
@@ -233,7 +238,7 @@ def main():
         sig_pxs = [(2.0 * torch.rand(6 * B, 3, 384, 384, device=dev) - 1.0) for _ in range(n_streams)]
         sig_px = sig_pxs[0]
         if args.workload == "robot":
-            tok_bufs = [torch.empty(6 * B, 729, 1152, dtype=rdt_dtype, device=dev) for _ in range(n_streams)]
+            tok_bufs = [torch.empty(6 * B, 729, 1152, dtype=rdt.compute_dtype, device=dev) for _ in range(n_streams)]
     setup_s = time.time() - t0
 
     def step(slot=0):
@@ -253,7 +258,7 @@ def main():
             # the robot step (franka_model_eef.py:283-313 + frank_inference_eef.py:495-533): 6 camera frames per chunk through the SigLIP tower
             # -> image tokens (cast to the RDT dtype) -> RDT chunk -> first T ticks x 10 EEF dims -> DINOv2 x2 + MLP + interpolant SDE
             tok = sig.forward(sig_px)                                            # [6B, 729, 1152] fp32
-            img_tok = _ops.cast(tok, rdt_dtype, out=tok_bufs[slot]).view(B, 6 * tok.shape[1], tok.shape[2])
+            img_tok = _ops.cast(tok, rdt.compute_dtype, out=tok_bufs[slot]).view(B, 6 * tok.shape[1], tok.shape[2])
             x0 = rng.normal_(xinit_bufs[slot], round_bf16=args.precision == "bf16")
             chunk = rdt.predict_action(rin["lang"], rin["mask"], img_tok, rin["state"], rin["amask"], rin["freq"], x_init=x0, return_fp32=True)
             out_holder["chunk"] = chunk
@@ -405,8 +410,10 @@ def main():
         "value": round(value, 2), "unit": "frames/s" if args.workload == "marker" else "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 4), "p50_step_latency_ms": round(p50, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (DINOv2 tower: IEEE fp16)" if args.precision == "bf16" else "fp32",
-        "dtypes": ({"rdt": "bf16 storage + bf16 MFMA, fp32 residual stream and accumulation", "dinov2": "IEEE fp16 storage + f16 MFMA, fp32 residual stream",
+        "dtype": ("bf16 model, 16-bit activations in IEEE fp16 (RDT-1B --rdt-compute f16, DINOv2 tower; same width and MFMA rate as bf16)" if args.rdt_compute == "f16"
+                  else "bf16 (DINOv2 tower: IEEE fp16)") if args.precision == "bf16" else "fp32",
+        "dtypes": ({"rdt": ("bf16 weights converted exactly to IEEE fp16, fp16 activations + f16 MFMA" if args.rdt_compute == "f16" else "bf16 storage + bf16 MFMA")
+                           + ", fp32 residual stream, accumulation and solver state", "dinov2": "IEEE fp16 storage + f16 MFMA, fp32 residual stream",
                     "siglip": "IEEE fp16 storage + f16 MFMA", "obs_mlp": "fp32", "unet_sampler": "fp32 storage, split-bf16 (3 bf16 MFMAs per product)",
                     "lstm_head": "fp32 storage, split-bf16"} if args.precision == "bf16" else {"all": "fp32 storage + fp32 MFMA"}),
         "data": "synthetic",
@@ -416,7 +423,7 @@ def main():
             "hipgraph": graph is not None, "batches_in_flight": n_streams, "inputs": "one synthetic input set per batch in flight (no sharing between slots)",
             "tactile_vector_dim": args.force_dim,
             "ms_per_step_semantics": "wall time of the timed region / steps; with batches_in_flight > 1 consecutive steps (independent batches) "
-                                     "overlap on separate HIP streams, so p50_step_latency_ms (enqueue -> completion of one batch) exceeds ms_per_step", "rdt_mode": "bf16 storage + bf16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32",
+                                     "overlap on separate HIP streams, so p50_step_latency_ms (enqueue -> completion of one batch) exceeds ms_per_step", "rdt_mode": (("IEEE fp16" if args.rdt_compute == "f16" else "bf16") + " storage + MFMA (bf16 model), fp32 residual stream") if args.precision == "bf16" else "fp32",
             "dino_mode": "IEEE fp16 storage + f16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32", "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
             "weights": "random-init synthetic of the named architectures (no checkpoints offline; RDT-1B hyper-parameters are upstream's, "
                        "not in the reference)", "setup_s": round(setup_s, 1),
@@ -572,9 +579,10 @@ def main():
             x_init = torch.randn(B, 64, 128, generator=gx, device=dev, dtype=torch.float32).to(rdt_dtype)
             zc = torch.randn(10, B, T, 10)
             with torch.cuda.stream(stream):
-                gpu_chunk = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init)
-                # the CHAIN of the step, on the same inputs: fp32 hand-over of the chunk -> first T ticks x 10 EEF dims -> predict (all B episodes)
+                # the chunk as the step hands it over (fp32 buffer of the solver), then the CHAIN of the step on the same inputs: first T ticks x 10 EEF
+                # dims -> predict (all B episodes)
                 chunk32 = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init, return_fp32=True)
+                gpu_chunk = chunk32
                 gpu_chain = ctrl.predict(inp["state"], _ops.slice_cast(chunk32, T, 10), inp["cam1"], inp["cam2"], inp["forces"], noise=zc.to(dev))
                 stream.synchronize()
             t1 = time.perf_counter()
@@ -615,7 +623,8 @@ def main():
                                         "chain_parity_note": "a_hat of episode 0: GPU RDT-1B bf16 chunk (B=%d) -> slice -> predict vs oracle chunk -> oracle predict, "
                                                              "same start noise and SDE noise; north-star tolerance 1e-2 (flat)" % B,
                                         "max_abs_diff_vs_gpu_rdt": rdt_diff, "rdt_output_scale": rdt_scale,
-                                        "rdt_parity_note": "GPU batch row 0 (bf16, B=%d) vs oracle fp32 on the same bf16-rounded weights / inputs / start noise" % B})
+                                        "rdt_parity_note": "GPU batch row 0 (bf16 model, %s activations, B=%d, fp32 hand-over) vs oracle fp32 on the same bf16-rounded weights / "
+                                                           "inputs / start noise" % (args.rdt_compute, B)})
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -58,7 +58,7 @@ int vt_pack_w32(const void* W, long ldw, void* out, int N, int K, vt_stream_t st
  * knob 7 = fused U-Net sampler path (vt_unet_fused_pack) on (1) / off (0: the launch-per-op driver);
  * knob 8 = persistent 256-square GEMM tile with the in-loop epilogue (csrc/vt_gemm_pt.hip) on (1) / off (0: gemm_pp256d_kernel);
  * knob 9 = grouped-query ViT self-attention (csrc/vt_attn.hip, attn16g_kernel: a block walks the keys once for G x 16 query rows per wave):
- *          0 off (attn16u_kernel), 1 on with G chosen per shape (default), 3 / 6 = G pinned. */
+ *          0 off (attn16u_kernel), 1 = 64-wide heads with at most 384 query rows (DINOv2 @224; default), 3 / 6 = every 16-bit unmasked call, G pinned. */
 int vt_tune(int knob, int value);
 
 /* Flash attention, head_dim 64 (or 96: params.hd): params = struct VtAttnParams (csrc/vt_kernels.h), host pointer.
@@ -238,6 +238,10 @@ int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n);
 /* 16-bit mode only: 1 (default) = DPM-Solver++ state, x0 predictions and the final projection in fp32 between network evaluations; 0 = the
  * reference's bf16 rounding points (models/rdt_runner.py:137-139,160: `noisy_action.to(dtype)` after every scheduler step). */
 int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state);
+/* 16-bit modes: the reference's dtype when it differs from the engine's compute type (desc.cdt = desc.adt = VT_F16 evaluating a bf16 model with IEEE
+ * fp16 activations — same width and MFMA rate, 3 more mantissa bits, the bf16 weights convert exactly): the start noise (models/rdt_runner.py:137-139)
+ * and, with vt_rdt_set_state_precision(h, 0), the solver state are rounded to THIS grid.  VT_BF16 (default for bf16 engines) or VT_F16. */
+int vt_rdt_set_io_dtype(vt_rdt_t h, int io_dtype);
 size_t vt_rdt_packed_bytes(vt_rdt_t h);
 int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream);
 /* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the

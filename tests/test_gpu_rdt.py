@@ -36,14 +36,15 @@ RUNNER_CFG = {"rdt": None, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_g
                                   "prediction_type": "sample", "clip_sample": False}}
 
 
-def make_runner(cfg, dtype, **over):
+def make_runner(cfg, dtype, compute=None, **over):
+    """compute: the 16-bit activation type of a bf16 runner ("f16" = the default, "bf16" = the reference's execution dtype)."""
     from models.rdt_runner import RDTRunner
     c = dict(RUNNER_CFG)
     c["rdt"] = {"hidden_size": cfg["hidden"], "depth": cfg["depth"], "num_heads": cfg["heads"]}
     c.update(over)
     r = RDTRunner(action_dim=cfg["action_dim"], pred_horizon=cfg["horizon"], config=c, lang_token_dim=cfg["lang_token_dim"],
                   img_token_dim=cfg["img_token_dim"], state_token_dim=cfg["state_token_dim"], max_lang_cond_len=cfg["max_lang_cond_len"],
-                  img_cond_len=cfg["img_cond_len"], dtype=dtype, device="cuda:0")
+                  img_cond_len=cfg["img_cond_len"], dtype=dtype, device="cuda:0", compute_dtype=compute)
     r.load_state_dict(cases.rdt_sd(cfg, torch.float32))
     return r
 
@@ -90,12 +91,15 @@ def test_rdt_forward_per_sample_timesteps_and_var_rmsnorm():
         assert err(y, ref.numpy()) < 2e-4 * max(1.0, float(ref.abs().max())), mode
 
 
-@pytest.mark.parametrize("dname,dtype", [("f32", torch.float32), ("bf16", torch.bfloat16)])
-def test_predict_action_vs_oracle_sampler(dname, dtype):
+@pytest.mark.parametrize("dname,dtype,compute", [("f32", torch.float32, None), ("bf16", torch.bfloat16, "bf16"), ("bf16", torch.bfloat16, "f16")])
+def test_predict_action_vs_oracle_sampler(dname, dtype, compute):
+    """bf16 model, both 16-bit activation types: "bf16" = the reference's execution dtype (held to the reference's own bf16 error), "f16" = the
+    default (bf16 weights converted exactly, IEEE fp16 activations: held to a 4x tighter bar)."""
     g = G(f"g9_rdt_sample_{dname}_UNPINNED")
     exact = G("g9_rdt_sample_f32_UNPINNED")["out"]
     cfg = cases.RDT_TINY
-    r = make_runner(cfg, dtype)
+    r = make_runner(cfg, dtype, compute=compute)
+    assert r.compute_dtype == {None: torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[compute]
     ri = cases.rdt_inputs(cfg, 2, 12, dtype=dtype)
     out = r.predict_action(ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"],
                            x_init=ri["x_init"])
@@ -106,8 +110,14 @@ def test_predict_action_vs_oracle_sampler(dname, dtype):
         assert err(out, g["out"]) < 2e-4 * max(1.0, scale), err(out, g["out"])
     else:
         e_hip, e_ref = err(out, exact), err(g["out"], exact)
-        print(f"scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |oracle16-exact| {e_ref:.3e}")
+        print(f"[compute {compute}] scale {scale:.2f}: |hip16-exact| {e_hip:.3e}  |oracle16-exact| {e_ref:.3e}")
         assert e_hip <= max(1e-2 * scale, 1.5 * e_ref), (e_hip, e_ref)
+        if compute == "f16":      # the result is returned in bf16 (the model's dtype): half a bf16 ulp of the scale is the floor
+            out32 = r.predict_action(ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"],
+                                     x_init=ri["x_init"], return_fp32=True)
+            e32 = err(out32, exact)
+            print(f"[compute f16, fp32 hand-over] |hip16-exact| {e32:.3e}")
+            assert e32 <= 2.5e-3 * scale, (e32, scale)
 
 
 def test_conditional_sample_equals_predict_action_and_errors():

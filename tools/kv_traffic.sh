@@ -28,6 +28,13 @@ print("%-34s %8s us   read %.2f GB  write %.2f GB  total %.2f GB  (algorithmic 0
 P
   rm -rf $O/$TAG
 }
+if [ "$1" = "ablate" ]; then      # timing-only: does the time follow the traffic?  A panel L2-resident (reads drop to the W stream), then also without stores
+  one default ""
+  one A_panel_resident "VLATOUCH_PT_ABL=128"
+  one A_resident_no_stores "VLATOUCH_PT_ABL=136"
+  one no_stores "VLATOUCH_PT_ABL=8"
+  one default_again ""
+else
 one default ""
 one store_nt "VLATOUCH_PT_ABL=16"
 one store_sc0nt "VLATOUCH_PT_ABL=32"
@@ -38,4 +45,5 @@ one gm2 "VLATOUCH_GEMM_GM=2"
 one gm8 "VLATOUCH_GEMM_GM=8"
 one gm8_both "VLATOUCH_GEMM_GM=8 VLATOUCH_PT_KV_SPLIT=0"
 one default_again ""
+fi
 cp /tmp/libvlatouch_hip.product.so vla-touch_amd/vlatouch/libvlatouch_hip.so

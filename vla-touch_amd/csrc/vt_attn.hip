@@ -996,29 +996,36 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   if (p.hd != 0 && p.hd != 64 && p.hd != 96 && p.hd != 80) return VT_ERR_UNSUPPORTED;
   // 16-bit, unmasked, 16-byte-aligned rows: DMA-staged double-buffered tiles (VLATOUCH_ATTN16=0 keeps attn_kernel for A/B)
   static const int a16 = [] { const char* e = getenv("VLATOUCH_ATTN16"); return e ? atoi(e) : 2; }();
-  // ViT-sized query counts (>= 128 rows: DINOv2 257 / 730 / 1370 tokens, SigLIP 729): the grouped-query kernel, whole (image, head) sequences per
-  // block where they fit (attn16g_kernel; VLATOUCH_ATTN16G=0 for A/B, =3 / =6 pins the groups per wave)
+  // Grouped-query kernel (attn16g_kernel, G = 6 query groups per wave, the key tiles walked once per block).  Measured (round 5, tools/attn_bench.py,
+  // EXPERIMENTS.md): DINOv2-B's 257 tokens as ONE block of 4 waves per (image, head): 48.8 us per layer against 54.4 for attn16u_kernel's three blocks
+  // (the six independent groups of a wave overlap their MFMA and softmax streams); the SAME nest on SigLIP's 729 tokens x 80-wide heads is SLOWER
+  // (G = 6: 1 459 us against 1 279 — 256 VGPRs + 23 spilled; G = 3, no spills, two blocks per (image, head): 1 308): staging K / V once is not what
+  // that launch is short of.  So: 64-wide heads and at most 24 query groups (Nq <= 384) take it, everything else stays on attn16u_kernel.
+  // vt_tune(9, v) / VLATOUCH_ATTN16G: 0 = never, 1 = that policy (default), 3 / 6 = every 16-bit unmasked call with G pinned (tests, A/B).
   if (g_vt_attn16g < 0) { const char* e = getenv("VLATOUCH_ATTN16G"); g_vt_attn16g = e ? atoi(e) : 1; }
   const int a16g = g_vt_attn16g;
   if (a16 && a16g && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nq >= 128 && (p.hd == 0 || p.hd == 64 || p.hd == 80)) {
-    // fewest blocks per (image, head), then fewest 16-row groups in them, then more waves (shorter chains per wave); G in {3, 6}
     const int need = (p.Nq + 15) / 16;
-    int bG = 0, bW = 0; long bcost = 1L << 60;
-    for (int G : {3, 6}) {
-      if (a16g == 3 || a16g == 6) { if (G != a16g) continue; }
+    int bG = 0, bW = 0;
+    if (a16g == 3 || a16g == 6) {                     // pinned: fewest blocks per (image, head), then fewest groups in them, then more waves
+      long bcost = 1L << 60;
       for (int w = 4; w <= 8; ++w) {
-        const int per = G * w, blocks = (need + per - 1) / per;
-        const long cost = ((long)blocks << 40) + ((long)(blocks * per - need) << 20) + (8 - w) * 64 + G;
-        if (cost < bcost) { bcost = cost; bG = G; bW = w; }
+        const int per = a16g * w, blocks = (need + per - 1) / per;
+        const long cost = ((long)blocks << 40) + ((long)(blocks * per - need) << 20) + (8 - w);
+        if (cost < bcost) { bcost = cost; bG = a16g; bW = w; }
       }
+    } else if (p.hd != 80 && need <= 24) {
+      bG = 6; bW = (need + 5) / 6 < 4 ? 4 : (need + 5) / 6;
     }
-    dim3 gg((need + bG * bW - 1) / (bG * bW), p.H, p.B);
+    if (bG) {
+      dim3 gg((need + bG * bW - 1) / (bG * bW), p.H, p.B);
 #define VT_A16G(T, HDv) do { if (bG == 6) hipLaunchKernelGGL((attn16g_kernel<T, HDv, 6>), gg, dim3(64 * bW), 0, s, p); \
                              else hipLaunchKernelGGL((attn16g_kernel<T, HDv, 3>), gg, dim3(64 * bW), 0, s, p); } while (0)
-    if (p.hd == 80) { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 80); else VT_A16G(half_t, 80); }
-    else { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 64); else VT_A16G(half_t, 64); }
+      if (p.hd == 80) { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 80); else VT_A16G(half_t, 80); }
+      else { if (p.dtype == VT_BF16) VT_A16G(bf16_t, 64); else VT_A16G(half_t, 64); }
 #undef VT_A16G
-    return vt_check_launch();
+      return vt_check_launch();
+    }
   }
   if (a16 && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nk >= 1) {
 #define VT_A16(KERN, T) do { if (p.hd == 96) hipLaunchKernelGGL((KERN<T, 96>), grid, dim3(64 * nw), 0, s, p); \

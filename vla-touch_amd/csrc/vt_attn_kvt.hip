@@ -1,4 +1,4 @@
-// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT, bf16).  The cache is a per-head TILE STREAM over the rows
+// vt_attn_kvt.hip — cross-attention against a CACHED condition (RDT; 16-bit: bf16 or IEEE fp16, template parameter T).  The cache is a per-head TILE STREAM over the rows
 // m = b*L + l of the whole batch (samples back to back):
 //   tile(h, t = m/64) at KV + (h*T + t) * 8192 elements = [K: 64 rows x 64 d (after k_norm)][Vt: 64 d x 64 rows]
 //   (Vt keys in MFMA k order: row kk of the tile sits at position vt_kpos(kk), see vt_kernels.h)
@@ -20,8 +20,18 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int KT = 64;                 // keys per tile
+typedef __attribute__((ext_vector_type(2))) _Float16 kvt_half2_t;
+template <typename T> __device__ __forceinline__ uint32_t kvt_pk(float lo, float hi);
+template <> __device__ __forceinline__ uint32_t kvt_pk<bf16_t>(float lo, float hi) { return pk_bf16(lo, hi); }
+template <> __device__ __forceinline__ uint32_t kvt_pk<half_t>(float lo, float hi) {
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){lo, hi}, kvt_half2_t));
+}
+template <typename T> struct KvtOne;      // 1.0 in the 16-bit type (the fragment of ones that sums P on the matrix pipe)
+template <> struct KvtOne<bf16_t> { static constexpr short v = 0x3f80; };
+template <> struct KvtOne<half_t> { static constexpr short v = 0x3c00; };
 constexpr int STAGE = 2 * KT * 128;    // K tile (64 rows x 128 B) + Vt tile (64 d-rows x 128 B) = 16 KiB
 
+template <typename T>
 __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) {
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -33,8 +43,8 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   // un-normalised partial (m, l, o) goes to `part_ws` and attn_combine_kernel merges the parts (flash-decoding)
   const int part = p.parts > 1 ? blockIdx.x : 0;
   const int q = (p.parts > 1 ? 0 : blockIdx.x * (nw * 16)) + wave * 16 + l15;
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
-  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + (long)h * p.T * 8192;
+  const uint16_t* Q = reinterpret_cast<const uint16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
+  const uint16_t* KV = reinterpret_cast<const uint16_t*>(p.KV) + (long)h * p.T * 8192;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
   const int row0 = b * p.Nk, row1 = row0 + p.Nk;             // this sample's rows of the stream
   int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
@@ -44,7 +54,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
     t_last = min(t_last, t_first + per - 1);
   }
 
-  Frag<bf16_t> qf[2];
+  Frag<T> qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
     qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -56,7 +66,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   const int r_in = lane >> 3, pch = lane & 7;
   auto stage = [&](int buf, int tile) {
     char* base = smem + buf * STAGE;
-    const bf16_t* src = KV + (long)tile * 8192;
+    const uint16_t* src = KV + (long)tile * 8192;
     if (wave >= 4) return;                     // waves 0..3 carry 4 consecutive pieces each (measured: 20 % faster streaming
 #pragma unroll                                 // than dealing the 16 pieces round-robin over all NW waves)
     for (int e = 0; e < 4; ++e) {
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
       sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        Frag<bf16_t> kf;
+        Frag<T> kf;
         lds_frag(kf, Ks, kt * 16 + l15, ks * 4 + g);
         mma16(sacc[kt], kf, qf[ks]);
       }
@@ -136,17 +146,17 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
     for (int kb = 0; kb < 2; ++kb) {
       // P fragment = this lane's own scores: k index j <-> key kb*32 + (j>>2)*16 + g*4 + (j&3)
       uint4 pw;
-      pw.x = pk_bf16(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
-      pw.y = pk_bf16(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
-      pw.z = pk_bf16(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
-      pw.w = pk_bf16(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
-      Frag<bf16_t> pf;
+      pw.x = kvt_pk<T>(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
+      pw.y = kvt_pk<T>(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
+      pw.z = kvt_pk<T>(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
+      pw.w = kvt_pk<T>(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
+      Frag<T> pf;
       pf.v = __builtin_bit_cast(short8_t, pw);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
         // the Vt tile stores its keys in the SAME k order (position g*8 + j inside each 32-key half), so the A fragment of
         // row d = dt*16 + l15 is one 16-byte chunk
-        Frag<bf16_t> vf;
+        Frag<T> vf;
         lds_frag(vf, Vs, dt * 16 + l15, kb * 4 + g);
         if (partial) {          // first / last tile of the sample: rows that are not its keys must not reach the MFMA
 #pragma unroll
@@ -174,12 +184,12 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
   }
   const float inv = 1.0f / l;
   if (q < p.Nq) {
-    bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
+    uint16_t* O = reinterpret_cast<uint16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint2 t;
-      t.x = pk_bf16(o[dt][0] * inv, o[dt][1] * inv);
-      t.y = pk_bf16(o[dt][2] * inv, o[dt][3] * inv);
+      t.x = kvt_pk<T>(o[dt][0] * inv, o[dt][1] * inv);
+      t.y = kvt_pk<T>(o[dt][2] * inv, o[dt][3] * inv);
       *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = t;
     }
   }
@@ -198,7 +208,7 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
 // traffic, no accumulator rescale, no data-dependent branch — 22 of the ~80 VALU instructions per 16 scores go; the row sum of P moves
 // to the matrix pipe (one extra MFMA per 32 keys against a fragment of ones: it sums exactly the bf16 P that multiplies V, and arrives
 // already reduced over all lanes), another 16 VALU adds.  The launcher falls back to the online form when B > 40.
-template <int RING, bool FIXED, int AUX = 0>
+template <typename T, int RING, bool FIXED, int AUX = 0>
 __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParams p) {
   constexpr int HALF = KT * 128;                     // 8 KiB
   __shared__ __attribute__((aligned(16))) char smem[RING * HALF];
@@ -209,8 +219,8 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   const int b = blockIdx.z, h = blockIdx.y;
   const int part = p.parts > 1 ? blockIdx.x : 0;
   const int q = (p.parts > 1 ? 0 : blockIdx.x * (nw * 16)) + wave * 16 + l15;
-  const bf16_t* Q = reinterpret_cast<const bf16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
-  const bf16_t* KV = reinterpret_cast<const bf16_t*>(p.KV) + (long)h * p.T * 8192;
+  const uint16_t* Q = reinterpret_cast<const uint16_t*>(p.Q) + (long)b * p.q_bs + (long)h * 64;
+  const uint16_t* KV = reinterpret_cast<const uint16_t*>(p.KV) + (long)h * p.T * 8192;
   const uint8_t* km = p.kmask ? p.kmask + (long)b * p.Nk : nullptr;
   const int row0 = b * p.Nk, row1 = row0 + p.Nk;
   int t_first = row0 >> 6, t_last = (row1 - 1) >> 6;
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   // a half tile = 8 pieces of 1 KiB (8 rows x 128 B); waves 0..3 issue 2 consecutive pieces each
   const int r_in = lane >> 3, pch = lane & 7;
   const int nh = t_first <= t_last ? 2 * (t_last - t_first + 1) : 0;
-  const bf16_t* hsrc = KV + (long)t_first * 8192;    // half hh of this block's range starts at hsrc + hh * 4096
+  const uint16_t* hsrc = KV + (long)t_first * 8192;    // half hh of this block's range starts at hsrc + hh * 4096
   auto stage_half = [&](int hh, int slot) {
     if (wave >= 4) return;
 #pragma unroll
@@ -252,10 +262,15 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
   float m_run = -INFINITY, l_run = 0.f;
   const float cscale = p.scale * 1.4426950408889634f;
-  const float fixed_mc = p.fixed_max * 1.4426950408889634f;      // FIXED: the bound is already in scaled-score units
+  // FIXED: the bound is already in scaled-score units.  IEEE fp16 probabilities have 5 exponent bits: exp(s - B) in (e^-2B, 1] would sit in (and below)
+  // the subnormals for every row whose largest score is well under the bound, so the fp16 form shifts the exponent up by 15 octaves (P in (2^15 e^-2B, 2^15],
+  // the largest finite fp16 is 65504): the row sum l carries the same factor and O / l cancels it; the launcher admits bounds up to 16 only (40 for bf16)
+  constexpr float P_SHIFT = std::is_same<T, half_t>::value ? 15.0f : 0.0f;
+  const float fixed_mc = p.fixed_max * 1.4426950408889634f - P_SHIFT;
   float4_t lacc = {0.f, 0.f, 0.f, 0.f};                           // FIXED: row sums of P on the matrix pipe (every row of the tile = l)
-  Frag<bf16_t> ones;
-  ones.v = (short8_t){0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+  Frag<T> ones;
+  constexpr short one16 = KvtOne<T>::v;
+  ones.v = (short8_t){one16, one16, one16, one16, one16, one16, one16, one16};
 
 #pragma unroll
   for (int hh = 0; hh < RING - 1; ++hh)
@@ -263,7 +278,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   // the Q fragments AFTER the first halves are on their way (one memory round trip before the first MFMA instead of two: the language
   // layers' launches are one tile long), and everything retired together: an ordinary load still pending when the ring runs would make the
   // compiler drain the whole queue (vmcnt(0)) at its first use anyway
-  Frag<bf16_t> qf[2];
+  Frag<T> qf[2];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks)
     qf[ks].v = q < p.Nq ? *reinterpret_cast<const short8_t*>(Q + (long)q * p.q_rs + ks * 32 + g * 8) : (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
@@ -288,7 +303,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
       sacc[kt] = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
-        Frag<bf16_t> kf;
+        Frag<T> kf;
         lds_frag(kf, Ks, kt * 16 + l15, ks * 4 + g);
         mma16(sacc[kt], kf, qf[ks]);
       }
@@ -334,14 +349,14 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
       for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
       l_run += psum;
     }
-    Frag<bf16_t> pf[2];
+    Frag<T> pf[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       uint4 pw;
-      pw.x = pk_bf16(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
-      pw.y = pk_bf16(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
-      pw.z = pk_bf16(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
-      pw.w = pk_bf16(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
+      pw.x = kvt_pk<T>(sv[(kb * 2) * 4 + 0], sv[(kb * 2) * 4 + 1]);
+      pw.y = kvt_pk<T>(sv[(kb * 2) * 4 + 2], sv[(kb * 2) * 4 + 3]);
+      pw.z = kvt_pk<T>(sv[(kb * 2 + 1) * 4 + 0], sv[(kb * 2 + 1) * 4 + 1]);
+      pw.w = kvt_pk<T>(sv[(kb * 2 + 1) * 4 + 2], sv[(kb * 2 + 1) * 4 + 3]);
       pf[kb].v = __builtin_bit_cast(short8_t, pw);
     }
     slot = next_slot(slot);
@@ -353,7 +368,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        Frag<bf16_t> vf;
+        Frag<T> vf;
         lds_frag(vf, Vs, dt * 16 + l15, kb * 4 + g);
         if (partial) {
 #pragma unroll
@@ -391,19 +406,20 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   }
   const float inv = 1.0f / l;
   if (q < p.Nq) {
-    bf16_t* O = reinterpret_cast<bf16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
+    uint16_t* O = reinterpret_cast<uint16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       uint2 t;
-      t.x = pk_bf16(o[dt][0] * inv, o[dt][1] * inv);
-      t.y = pk_bf16(o[dt][2] * inv, o[dt][3] * inv);
+      t.x = kvt_pk<T>(o[dt][0] * inv, o[dt][1] * inv);
+      t.y = kvt_pk<T>(o[dt][2] * inv, o[dt][3] * inv);
       *reinterpret_cast<uint2*>(O + dt * 16 + g * 4) = t;
     }
   }
 }
 
 // merge the key-range parts of a (batch, head): O = sum_p e^{(m_p - m) c} o_p / sum_p e^{(m_p - m) c} l_p, c = scale*log2(e) (exp2 domain, as above)
-__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_ws, bf16_t* __restrict__ O, long o_bs, long o_rs, int H, int Nq, int rows_pad,
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_ws, uint16_t* __restrict__ O, long o_bs, long o_rs, int H, int Nq, int rows_pad,
                                                           int parts, float cscale) {
   // one thread per (row, group of 4 d): 16 rows x 16 groups per block, grid.x blocks of 16 rows (at batch 1 a single block per (b, h) walked
   // 67 x 16 items serially: 38 us per call, 2.6 ms of the 31 ms robot step)
@@ -438,8 +454,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   }
   const float inv = 1.0f / l;
   uint2 t;
-  t.x = pk_bf16(acc[0] * inv, acc[1] * inv);
-  t.y = pk_bf16(acc[2] * inv, acc[3] * inv);
+  t.x = kvt_pk<T>(acc[0] * inv, acc[1] * inv);
+  t.y = kvt_pk<T>(acc[2] * inv, acc[3] * inv);
   *reinterpret_cast<uint2*>(O + (long)b * o_bs + (long)row * o_rs + h * 64 + d4) = t;
 }
 
@@ -526,6 +542,8 @@ int vt_attn_kvt_fixed_enabled() { attn_env_once(); return g_vt_attn_fixed; }
 
 int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   if (p.B <= 0 || p.H <= 0 || p.Nq <= 0 || p.Nk <= 0 || (long)p.T * 64 < (long)p.B * p.Nk || p.q_rs % 8) return VT_ERR_ARG;
+  if (p.dtype != 0 && p.dtype != VT_BF16 && p.dtype != VT_F16) return VT_ERR_UNSUPPORTED;
+  const bool f16 = p.dtype == VT_F16;             // 0 (unset) = bf16
   int nw = 4, best = 1 << 30;
   for (int w = 4; w <= 8; ++w) {
     const int rows = w * 16, padded = (p.Nq + rows - 1) / rows * rows;
@@ -539,30 +557,34 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
   // fixed-maximum softmax (see attn_kvt_ring_kernel): only with a finite load-time bound small enough that exp(-2B) stays a normal number
   attn_env_once();
-  const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= 40.f;
+  const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= (f16 ? 16.f : 40.f);
   // A/B: extra (unused) dynamic LDS per block lowers the blocks per CU from 4 (4 x 40 KiB = the whole CU) so that a GEMM block of the other in-flight
   // batch can share the CU (VLATOUCH_ATTN_LDS_PAD bytes: 13000 -> 3 blocks, 40000 -> 2 blocks)
   static const int lds_pad = [] { const char* e = getenv("VLATOUCH_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
   // nt cache policy (aux = 2) on the K / Vt tile DMA: every tile is read once per launch and the stream (16 GB over the 14 image layers) outlives every
   // cache — 121 -> 104 us per launch averaged over the layers (62 -> 72 % of the HBM roof), full 423 -> 431 chunks/s; VLATOUCH_KVT_NT=0 for A/B
   static const int kv_nt = [] { const char* e = getenv("VLATOUCH_KVT_NT"); return e ? atoi(e) : 1; }();
-#define VT_KVT_GO(grid) \
-  do { if (fixed && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
-       else if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, true>), grid, dim3(64 * nw), lds_pad, s, p); \
-       else if (ring == 5 && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
-       else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<5, false>), grid, dim3(64 * nw), lds_pad, s, p); \
-       else if (ring == 4) hipLaunchKernelGGL((attn_kvt_ring_kernel<4, false>), grid, dim3(64 * nw), 0, s, p); \
-       else if (ring == 3) hipLaunchKernelGGL((attn_kvt_ring_kernel<3, false>), grid, dim3(64 * nw), 0, s, p); \
-       else hipLaunchKernelGGL(attn_kvt_kernel, grid, dim3(64 * nw), 0, s, p); } while (0)
+#define VT_KVT_GO_T(T, grid) \
+  do { if (fixed && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 5, true, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (fixed) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 5, true>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (ring == 5 && kv_nt) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 5, false, 2>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (ring == 5) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 5, false>), grid, dim3(64 * nw), lds_pad, s, p); \
+       else if (ring == 4) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 4, false>), grid, dim3(64 * nw), 0, s, p); \
+       else if (ring == 3) hipLaunchKernelGGL((attn_kvt_ring_kernel<T, 3, false>), grid, dim3(64 * nw), 0, s, p); \
+       else hipLaunchKernelGGL(attn_kvt_kernel<T>, grid, dim3(64 * nw), 0, s, p); } while (0)
+#define VT_KVT_GO(grid) do { if (f16) VT_KVT_GO_T(half_t, grid); else VT_KVT_GO_T(bf16_t, grid); } while (0)
   if (p.parts > 1) {
     if (qblocks != 1 || !p.part_ws || p.parts > 16) return VT_ERR_ARG;
     VT_KVT_GO(dim3(p.parts, p.H, p.B));
-    hipLaunchKernelGGL(attn_combine_kernel, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (bf16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
-                       p.scale * 1.4426950408889634f);
+    if (f16) hipLaunchKernelGGL(attn_combine_kernel<half_t>, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (uint16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
+                                p.scale * 1.4426950408889634f);
+    else hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (uint16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
+                            p.scale * 1.4426950408889634f);
     return vt_check_launch();
   }
   dim3 grid(qblocks, p.H, p.B);
   VT_KVT_GO(grid);
+#undef VT_KVT_GO_T
 #undef VT_KVT_GO
   return vt_check_launch();
 }

@@ -141,7 +141,7 @@ bool vt_gemm_fast_eligible(const VtGemmParams& p) {
   if (p.c_dtype != p.a_dtype && p.c_dtype != VT_F32) return false;
   if (p.K % BK || p.lda % 8 || p.ldw % 8 || p.N % 4 || p.ldc % 4 || (p.residual && p.ldr % 4)) return false;
   if (p.M < 128) return false;
-  if (p.cmap && (p.a_dtype != VT_BF16 || p.c_dtype == VT_F32 || p.N % 64 || p.residual || p.groups != 1 || (long)p.cmap_T * 64 < p.M)) return false;
+  if (p.cmap && ((p.a_dtype != VT_BF16 && !(p.a_dtype == VT_F16 && p.cmap == 3)) || p.c_dtype == VT_F32 || p.N % 64 || p.residual || p.groups != 1 || (long)p.cmap_T * 64 < p.M)) return false;
   if (p.cmap == 3 && (p.N % 128)) return false;      // fused K|V: two halves of whole heads
   const long tiles = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.groups;
   return tiles >= 96;
@@ -198,7 +198,8 @@ int vt_gemm_fast_launch(const VtGemmParams& p, hipStream_t s) {
 #define VT_FAST_GO3(T16, TC) \
   { if (bm == 128) VT_FAST_GO(T16, TC, 128); else VT_FAST_GO(T16, TC, 64); }
 #define VT_FAST_GO_CMAP(BMv) \
-  { if (p.cmap == 1) launch_variant<bf16_t, bf16_t, BMv, 1>(variant, dim3(total), s, p, tiles_n, per_group, total); \
+  { if (p.a_dtype == VT_F16) launch_variant<half_t, half_t, BMv, 3>(variant, dim3(total), s, p, tiles_n, per_group, total);      /* fp16: the fused K|V form only */ \
+    else if (p.cmap == 1) launch_variant<bf16_t, bf16_t, BMv, 1>(variant, dim3(total), s, p, tiles_n, per_group, total); \
     else if (p.cmap == 2) launch_variant<bf16_t, bf16_t, BMv, 2>(variant, dim3(total), s, p, tiles_n, per_group, total); \
     else launch_variant<bf16_t, bf16_t, BMv, 3>(variant, dim3(total), s, p, tiles_n, per_group, total); }
   const bool c16 = p.c_dtype != VT_F32;

@@ -333,7 +333,8 @@ int vt_gemm_pp_launch(const VtGemmParams& p, hipStream_t s) {
 #define VT_PP_GO(T16, TC, CM) do { if (deep) hipLaunchKernelGGL((gemm_pp256d_kernel<T16, TC, CM>), dim3(total), dim3(512), 0, s, p, tiles_n, per_group, total, gm); \
                                    else hipLaunchKernelGGL((gemm_pp256_kernel<T16, TC, CM>), dim3(total), dim3(512), 0, s, p, tiles_n, per_group, total, gm); } while (0)
   const bool c16 = p.c_dtype != VT_F32;
-  if (p.cmap == 1) VT_PP_GO(bf16_t, bf16_t, 1);
+  if (p.cmap == 3 && p.a_dtype == VT_F16) VT_PP_GO(half_t, half_t, 3);
+  else if (p.cmap == 1) VT_PP_GO(bf16_t, bf16_t, 1);
   else if (p.cmap == 2) VT_PP_GO(bf16_t, bf16_t, 2);
   else if (p.cmap == 3) VT_PP_GO(bf16_t, bf16_t, 3);
   else if (p.a_dtype == VT_BF16) { if (c16) VT_PP_GO(bf16_t, bf16_t, 0); else VT_PP_GO(bf16_t, float, 0); }

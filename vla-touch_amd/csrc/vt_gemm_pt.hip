@@ -647,7 +647,7 @@ static bool pt_kind_ok(const VtGemmParams& p) {
   if (p.c_dtype == VT_F32)          // R32 kind: fp32 C = residual + colscale * (acc + bias)
     return p.residual && p.colscale && p.cmap == 0 && !p.hn_w0 && !p.hn_w1 && p.act == VT_ACT_NONE && (long)p.ldc * 4 * 128 < (1L << 31) && (long)p.ldr * 4 * 128 < (1L << 31);
   if (p.residual || p.colscale) return false;
-  if (p.cmap == 3) return p.a_dtype == VT_BF16 && (p.N % 512) == 0 && p.hn_c0_end == (p.N >> 1) && !p.hn_w1 && p.act == VT_ACT_NONE && p.hn_w0;
+  if (p.cmap == 3) return (p.a_dtype == VT_BF16 || p.a_dtype == VT_F16) && (p.N % 512) == 0 && p.hn_c0_end == (p.N >> 1) && !p.hn_w1 && p.act == VT_ACT_NONE && p.hn_w0;
   if (p.cmap != 0 || p.hn_w0 || p.hn_w1) return false;
   if ((long)p.ldc * 2 * 128 >= (1L << 31)) return false;
   return p.act == VT_ACT_NONE || p.act == VT_ACT_GELU_ERF || p.act == VT_ACT_GELU_TANH;
@@ -712,7 +712,7 @@ int vt_gemm_pt_launch(const VtGemmParams& p, hipStream_t s) {
   { const char* e = getenv("VLATOUCH_PT_ABL"); g_pt_abl = e ? atoi(e) : 0; }
 #endif
 #define VT_PT_GO(T16, KIND, ACT) hipLaunchKernelGGL((gemm_pt_kernel<T16, KIND, ACT>), dim3(grid), dim3(512), 0, s, p, tiles_n, tiles_m, total, gm, g_pt_abl | (role_bit << 8) | (kv_split ? (1 << 12) : 0))
-  if (p.cmap == 3) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE);
+  if (p.cmap == 3) { if (p.a_dtype == VT_BF16) VT_PT_GO(bf16_t, KIND_KV, VT_ACT_NONE); else VT_PT_GO(half_t, KIND_KV, VT_ACT_NONE); }
   else if (p.c_dtype == VT_F32) { if (p.a_dtype == VT_BF16) VT_PT_GO(bf16_t, KIND_R32, VT_ACT_NONE); else VT_PT_GO(half_t, KIND_R32, VT_ACT_NONE); }
   else if (p.a_dtype == VT_BF16) {
     if (p.act == VT_ACT_NONE) VT_PT_GO(bf16_t, KIND_P16, VT_ACT_NONE);

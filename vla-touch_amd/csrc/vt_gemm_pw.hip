@@ -312,7 +312,10 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
         const float q1 = row16_sum(ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f);           // the variance form of the consumer also needs the row sum
         if (ok) {
           vt_epi_st128(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n, make_float4(o[0], o[1], o[2], o[3]));
-          T16 ov[4] = {Elem<T16>::from_f(o[0] * g4.x), Elem<T16>::from_f(o[1] * g4.y), Elem<T16>::from_f(o[2] * g4.z), Elem<T16>::from_f(o[3] * g4.w)};
+          // x * gain is NOT normalised yet (the consumer applies rstd): in IEEE fp16 a residual-stream outlier could leave the range — saturate instead of inf
+          constexpr float LIM = std::is_same<T16, half_t>::value ? 65504.0f : 3.0e38f;
+          auto sat = [](float v) { return fminf(fmaxf(v, -LIM), LIM); };
+          T16 ov[4] = {Elem<T16>::from_f(sat(o[0] * g4.x)), Elem<T16>::from_f(sat(o[1] * g4.y)), Elem<T16>::from_f(sat(o[2] * g4.z)), Elem<T16>::from_f(sat(o[3] * g4.w))};
           vt_epi_st64(Xn + (long)m * p.xn_ld + n, *reinterpret_cast<const uint2*>(ov));
         }
         if (c4 == 0 && m < p.M) *reinterpret_cast<float2*>(p.xn_part + ((long)m * pn + pcol) * 2) = make_float2(q, q1);

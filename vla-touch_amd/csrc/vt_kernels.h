@@ -41,6 +41,7 @@ struct VtAttnKvtParams {
   int parts;                  // > 1: split every sample's key tiles over `parts` blocks (needs Nq <= 16*NW and part_ws), merged by a 2nd kernel
   float* part_ws;             // [B][H][parts][16*NW rows][66] floats
   float fixed_max;            // > 0: an upper bound of |q . k| * scale known at load time (per-head RMS-normed q and k) -> fixed-maximum softmax; 0 = online
+  int dtype;                  // VT_BF16 (or 0) / VT_F16: the 16-bit type of Q, the tile stream and O
 };
 // bytes of part_ws for vt_attn_kvt_launch with `parts` parts
 inline size_t vt_attn_kvt_part_bytes(int B, int H, int Nq, int parts) { return parts > 1 ? (size_t)B * H * parts * ((Nq + 15) / 16 * 16 + 16) * 66 * 4 : 0; }

@@ -28,7 +28,16 @@
 #include "../../include/vlatouch.h"
 
 #define CK(x) do { int _r = (x); if (_r) return _r; } while (0)
-static int es(int dt) { return dt == VT_BF16 ? 2 : 4; }
+static int es(int dt) { return dt == VT_F32 ? 4 : 2; }
+static bool is16(int dt) { return dt == VT_BF16 || dt == VT_F16; }
+// element i of a buffer of type dt (VT_F32 / VT_BF16 / VT_F16) as float, and back; rnd16 = round to that type's grid
+__device__ __forceinline__ float ldx(const void* p, long i, int dt) {
+  return dt == VT_F32 ? ((const float*)p)[i] : dt == VT_F16 ? h2f(((const half_t*)p)[i]) : bf2f(((const bf16_t*)p)[i]);
+}
+__device__ __forceinline__ float rnd16(float v, int dt) { return dt == VT_F32 ? v : dt == VT_F16 ? h2f(f2h(v)) : bf2f(f2bf(v)); }
+__device__ __forceinline__ void stx(void* p, long i, float v, int dt) {
+  if (dt == VT_F32) ((float*)p)[i] = v; else if (dt == VT_F16) ((half_t*)p)[i] = f2h(v); else ((bf16_t*)p)[i] = f2bf(v);
+}
 
 namespace {
 struct Blk {
@@ -59,7 +68,8 @@ struct vt_rdt_s {
   const float *normf, *ffc1_b, *ffc2_b;
   const void *ffc1_w, *ffc2_w;
   const void *ffc1_wp, *ffc2_wp, *t_w1p, *t_w2p;      // + the small per-step Linears (timestep embedder, final projection; state adaptor: Adaptor::wp)
-  int state_f32 = 1;            // bf16 mode: keep the solver state, the network's x0 output and the final projection in fp32 (vt_rdt_set_state_precision)
+  int io_dt = VT_BF16;          // 16-bit modes: the grid the start noise (and, with state_f32 = 0, the solver state) is rounded to = the reference's dtype
+  int state_f32 = 1;            // 16-bit modes: keep the solver state, the network's x0 output and the final projection in fp32 (vt_rdt_set_state_precision)
   float score_bound[64];        // per block: upper bound of |q . k| * scale in its cross-attention (vt_rdt_set_score_bounds), 0 = unknown
   Adaptor lang, img, state;
 };
@@ -73,12 +83,13 @@ int vt_rdt_create(const vt_rdt_desc* desc, const void* const* w, int n, vt_rdt_t
     return vt_fail(VT_ERR_ARG, "vt_rdt_create: unsupported config (head_dim must be 64)");
   if (d.n_lang < 1 || d.n_lang > 4 || d.n_img < 1 || d.n_img > 4 || d.n_state < 1 || d.n_state > 4) return vt_fail(VT_ERR_ARG, "vt_rdt_create: adaptor depth 1..4");
   if (d.lang_dim % 16 || d.img_dim % 16 || (2 * d.state_dim) % 16) return vt_fail(VT_ERR_ARG, "vt_rdt_create: token dims must be multiples of 16");
-  if (d.cdt != d.adt || (d.cdt != VT_F32 && d.cdt != VT_BF16)) return vt_fail(VT_ERR_ARG, "vt_rdt_create: cdt == adt in {fp32, bf16}");
+  if (d.cdt != d.adt || (d.cdt != VT_F32 && !is16(d.cdt))) return vt_fail(VT_ERR_ARG, "vt_rdt_create: cdt == adt in {fp32, bf16, fp16}");
   if (n != vt_rdt_num_weights(desc)) return vt_fail(VT_ERR_ARG, "vt_rdt_create: expected %d weights, got %d", vt_rdt_num_weights(desc), n);
   for (int k = 0; k < n; ++k) if (!w[k]) return vt_fail(VT_ERR_ARG, "vt_rdt_create: weight %d is null", k);
   vt_rdt_s* h = new (std::nothrow) vt_rdt_s();
   if (!h) return vt_fail(-12, "out of host memory");
   h->d = d;
+  h->io_dt = d.adt == VT_F16 ? VT_F16 : VT_BF16;
   int i = 0;
   auto F = [&]() { return (const float*)w[i++]; };
   h->t_w1 = w[i++]; h->t_b1 = F(); h->t_w2 = w[i++]; h->t_b2 = F();
@@ -112,6 +123,14 @@ int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n) {
 // writes fp32, the x0 predictions and the solver state stay fp32 (only the copy fed to the action-token adaptor is rounded, as any bf16 GEMM operand is) —
 // strictly closer to the fp32 reference (at RDT-1B, B = 32: |chunk - oracle| 7.7e-3 -> see DESIGN.md section 3).  fp32_state = 0: the reference's own
 // rounding points in bf16 (`noisy_action.to(dtype)` after every scheduler step, rdt_runner.py:160; bf16 model output).  No effect in fp32 mode.
+// The reference's dtype when it differs from the engine's 16-bit compute type: a bf16 model evaluated with IEEE fp16 activations (adt = cdt = VT_F16:
+// same width and MFMA rate, 3 more mantissa bits; the bf16 weights convert exactly) still draws / rounds its start noise — and, with the reference's
+// rounding points, its solver state — on the bf16 grid.  io_dtype in {VT_BF16, VT_F16}.
+int vt_rdt_set_io_dtype(vt_rdt_t h, int io_dtype) {
+  if (!h || (io_dtype != VT_BF16 && io_dtype != VT_F16)) return vt_fail(VT_ERR_ARG, "vt_rdt_set_io_dtype: bf16 or fp16");
+  h->io_dt = io_dtype;
+  return VT_OK;
+}
 int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state) {
   if (!h) return vt_fail(VT_ERR_ARG, "vt_rdt_set_state_precision: null handle");
   h->state_f32 = fp32_state ? 1 : 0;
@@ -123,7 +142,7 @@ int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state) {
 // on `stream`.  Returns 0 bytes when the configuration has no use for them (fp32 mode, hidden size not a multiple of 512).
 static bool pk_ok(int N, int K) { return N % 64 == 0 && K % 256 == 0; }      // what vt_gemm_pws.hip / vt_gemm_pw.hip can take
 size_t vt_rdt_packed_bytes(vt_rdt_t h) {
-  if (!h || h->d.cdt != VT_BF16 || h->d.hidden % 512) return 0;
+  if (!h || !is16(h->d.cdt) || h->d.hidden % 512) return 0;
   const size_t D = h->d.hidden, DD = D * D * 2;
   size_t n = (size_t)h->d.depth * 8 * DD + DD;                                // blocks + final fc1
   if (pk_ok(h->d.out_dim, (int)D)) n += (size_t)h->d.out_dim * D * 2;           // final fc2
@@ -185,7 +204,7 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
   // row-major [R][2D] scratch of the K | V product of a condition that falls off the large-GEMM path (few rows: the language tokens at batch 1..3,
   // every condition of the tiny test configs) — its own buffer: 2 R D elements do not fit tmpA when 2 R > max(Li, L) * B
   { size_t rs = 0;
-    if (d.adt == VT_BF16) for (int R : {B * L, B * Li}) if (!vt_gemm_can_fuse_headnorm(cond_kv_params(d, R)) && (size_t)R > rs) rs = (size_t)R;
+    if (is16(d.adt)) for (int R : {B * L, B * Li}) if (!vt_gemm_can_fuse_headnorm(cond_kv_params(d, R)) && (size_t)R > rs) rs = (size_t)R;
     w.kv_small = take(rs * 2 * D * a); }
   w.state_tok = take((size_t)B * D * a); w.freq_emb = take((size_t)B * D * a); w.t_emb = take((size_t)B * D * a);
   w.emb_tmp = take((size_t)B * D * a); w.sin = take((size_t)B * 256 * a);
@@ -343,8 +362,8 @@ int cache_cond(RCtx& c) {
     const int Lc = lang ? c.L : d.img_len;
     char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
     const void* src = lang ? c.ws + c.w.lang_c : c.ws + c.w.img_c;
-    if (d.adt == VT_BF16) {
-      // bf16: K (k_norm fused) and V go straight from the GEMM epilogues into the tile stream when the projection takes the
+    if (is16(d.adt)) {
+      // 16-bit: K (k_norm fused) and V go straight from the GEMM epilogues into the tile stream when the projection takes the
       // large-GEMM path; small shapes go row-major through tmpA / tmpB and the retile kernels.
       const int T = lpad64(c.B * Lc) / 64;
       // one launch per layer: K | V fused (N = 2D), both halves of the tile stream written from ONE pass over the condition rows
@@ -380,7 +399,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
   const bool lang = (l % 2) == 0;
   const int Lc = lang ? c.L : d.img_len;
   const char* kv = lang ? c.ws + c.w.kv_lang + (size_t)(l / 2) * c.w.kv_lang_blk : c.ws + c.w.kv_img + (size_t)(l / 2) * c.w.kv_img_blk;
-  if (d.adt == VT_BF16) {
+  if (is16(d.adt)) {
     VtAttnKvtParams p;
     memset(&p, 0, sizeof(p));
     p.Q = c.ws + c.w.q; p.KV = kv; p.O = c.ws + c.w.att;
@@ -388,6 +407,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
     p.kmask = lang ? lang_mask : nullptr;
     p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(c.B * Lc) / 64; p.scale = 0.125f;
     p.fixed_max = c.h->score_bound[l];
+    p.dtype = d.adt;
     if (c.w.attn_parts > 1 && Lc >= 64 * 2 * c.w.attn_parts) { p.parts = c.w.attn_parts; p.part_ws = (float*)(c.ws + c.w.attn_part); }
     return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
   }
@@ -484,7 +504,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
 
 // x[b][0] = t_emb[b|0], x[b][1] = freq_emb[b], x[b][2] = state token, x[b][3..] = action tokens; + x_pos (model.py:141-148)
 __global__ void assemble_x_kernel(float* __restrict__ x, const void* t_emb, int t_bcast, const void* f_emb, const void* state_tok, long state_bs,
-                                  const void* act_tok, long act_bs, const float* __restrict__ pos, int B, int N, int D, int is_bf16) {
+                                  const void* act_tok, long act_bs, const float* __restrict__ pos, int B, int N, int D, int dt) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * N * D) return;
   const int dcol = (int)(i % D);
@@ -495,71 +515,64 @@ __global__ void assemble_x_kernel(float* __restrict__ x, const void* t_emb, int 
   else if (n == 1) { src = f_emb; off = (long)b * D + dcol; }
   else if (n == 2) { src = state_tok; off = (long)b * state_bs + dcol; }
   else { src = act_tok; off = (long)b * act_bs + (long)(n - 3) * D + dcol; }
-  const float v = is_bf16 ? bf2f(((const bf16_t*)src)[off]) : ((const float*)src)[off];
-  x[i] = v + pos[(long)n * D + dcol];
+  x[i] = ldx(src, off, dt) + pos[(long)n * D + dcol];
 }
 
 // out[b][l][:] = cond[b][l][:] + pos[l][:]   (model.py:150-152), all in the activation dtype
-__global__ void add_pos_kernel(const void* cond, const void* pos, void* out, int B, int Lc, int D, int is_bf16) {
+__global__ void add_pos_kernel(const void* cond, const void* pos, void* out, int B, int Lc, int D, int dt) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Lc * D) return;
   const long pl = i % ((long)Lc * D);
-  if (is_bf16) ((bf16_t*)out)[i] = f2bf(bf2f(((const bf16_t*)cond)[i]) + bf2f(((const bf16_t*)pos)[pl]));
-  else ((float*)out)[i] = ((const float*)cond)[i] + ((const float*)pos)[pl];
+  stx(out, i, ldx(cond, i, dt) + ldx(pos, pl, dt), dt);
 }
 
 // dst = src rounded to the activation dtype's grid (bf16 mode: noisy_action lives in bf16, rdt_runner.py:137-139,160; fp32 mode: a plain copy) —
 // the solver state's first value, taken from the caller's start noise in one kernel (no runtime copy kernel in the step)
-__global__ void take_xinit_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int is_bf16) {
+__global__ void take_xinit_kernel(const float* __restrict__ src, float* __restrict__ dst, long n, int round_dt) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = is_bf16 ? bf2f(f2bf(src[i])) : src[i];
+  if (i < n) dst[i] = rnd16(src[i], round_dt);
 }
 
 // sa_in[b][t] = cat(noisy[b][t] (adt copy of the fp32 master), mask[b])   (rdt_runner.py:148)
-__global__ void build_sa_in_kernel(const float* __restrict__ noisy, const void* mask, void* out, int B, int Hh, int S, int is_bf16) {
+__global__ void build_sa_in_kernel(const float* __restrict__ noisy, const void* mask, void* out, int B, int Hh, int S, int dt) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * 2 * S) return;
   const int c = (int)(i % (2 * S));
   const long r = i / (2 * S);
   const int b = (int)(r / Hh);
   float v;
-  if (c < S) {
-    v = noisy[r * S + c];
-    if (is_bf16) v = bf2f(f2bf(v));
-  } else {
-    v = is_bf16 ? bf2f(((const bf16_t*)mask)[(long)b * S + c - S]) : ((const float*)mask)[(long)b * S + c - S];
-  }
-  if (is_bf16) ((bf16_t*)out)[i] = f2bf(v); else ((float*)out)[i] = v;
+  if (c < S) v = noisy[r * S + c];
+  else v = ldx(mask, (long)b * S + c - S, dt);
+  stx(out, i, v, dt);
 }
 
 // x0 = out_tok[:, -horizon:, :]  (model.py:164) gathered contiguous
-__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_bf16) {      // is_bf16: both buffers 16-bit, else both fp32
+__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_16) {      // is_16: both buffers 16-bit (a plain copy), else both fp32
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
   const long r = i / S;
   const int t = (int)(r % Hh), b = (int)(r / Hh);
   const long src = ((long)b * N + (N - Hh) + t) * S + c;
-  if (is_bf16) ((bf16_t*)x0)[i] = ((const bf16_t*)out_tok)[src]; else ((float*)x0)[i] = ((const float*)out_tok)[src];
+  if (is_16) ((uint16_t*)x0)[i] = ((const uint16_t*)out_tok)[src]; else ((float*)x0)[i] = ((const float*)out_tok)[src];
 }
 
-// noisy = round(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163).  x0_bf16: storage type of the x0 buffers; round_bf16:
-// the reference's `noisy_action.to(dtype)` after every step (off when the solver state is kept in fp32); mask_bf16: storage type of the action mask
+// noisy = round(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163).  x0_dt: storage type of the x0 buffers; round_dt: the
+// reference's `noisy_action.to(dtype)` after every step (VT_F32 = none: the solver state is kept in fp32); mask_dt: storage type of the action mask
 __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, const void* x0p, float a, float b0, float b1, const void* mask, int last,
-                                  int B, int Hh, int S, int x0_bf16, int round_bf16, int mask_bf16, int sample_pred, float alpha_s, float sigma_s, void* x0_store,
+                                  int B, int Hh, int S, int x0_dt, int round_dt, int mask_dt, int sample_pred, float alpha_s, float sigma_s, void* x0_store,
                                   float* __restrict__ out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
   const int b = (int)(i / ((long)Hh * S));
-  float m0 = x0_bf16 ? bf2f(((const bf16_t*)x0)[i]) : ((const float*)x0)[i];
+  float m0 = ldx(x0, i, x0_dt);
   if (!sample_pred) m0 = (noisy[i] - sigma_s * m0) / alpha_s;          // epsilon prediction -> x0
-  if (x0_store) { if (x0_bf16) ((bf16_t*)x0_store)[i] = f2bf(m0); else ((float*)x0_store)[i] = m0; }
+  if (x0_store) stx(x0_store, i, m0, x0_dt);
   float v = a * noisy[i] + b0 * m0;
-  if (x0p) v += b1 * (x0_bf16 ? bf2f(((const bf16_t*)x0p)[i]) : ((const float*)x0p)[i]);
-  if (round_bf16) v = bf2f(f2bf(v));                                // `noisy_action.to(state_traj.dtype)` (rdt_runner.py:160)
-  if (last) v *= mask_bf16 ? bf2f(((const bf16_t*)mask)[(long)b * S + c]) : ((const float*)mask)[(long)b * S + c];
-  if (last && round_bf16) v = bf2f(f2bf(v));
+  if (x0p) v += b1 * ldx(x0p, i, x0_dt);
+  v = rnd16(v, round_dt);                                           // `noisy_action.to(state_traj.dtype)` (rdt_runner.py:160)
+  if (last) v = rnd16(v * ldx(mask, (long)b * S + c, mask_dt), round_dt);
   noisy[i] = v;
   if (out) out[i] = v;                                              // the last step also writes the caller's buffer
 }
@@ -584,10 +597,10 @@ int vt_rdt_forward(vt_rdt_t h, const void* x_tokens, const float* freq, const fl
   CK(make_rctx(c, h, B, L, workspace, stream));
   if (hipMemsetAsync(c.ws + c.w.sk_cnt, 0, RDT_SK_CNT * sizeof(int), c.s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "ticket counters");
   const vt_rdt_desc& d = h->d;
-  const int D = d.hidden, N = d.horizon + 3, bf = d.adt == VT_BF16;
+  const int D = d.hidden, N = d.horizon + 3, dt = d.adt;
   // conditions + position embeddings (model.py:150-152)
-  hipLaunchKernelGGL(add_pos_kernel, g1((long)B * L * D), dim3(256), 0, c.s, lang_c, h->lang_pos, (void*)(c.ws + c.w.lang_c), B, L, D, bf);
-  hipLaunchKernelGGL(add_pos_kernel, g1((long)B * d.img_len * D), dim3(256), 0, c.s, img_c, h->img_pos, (void*)(c.ws + c.w.img_c), B, d.img_len, D, bf);
+  hipLaunchKernelGGL(add_pos_kernel, g1((long)B * L * D), dim3(256), 0, c.s, lang_c, h->lang_pos, (void*)(c.ws + c.w.lang_c), B, L, D, dt);
+  hipLaunchKernelGGL(add_pos_kernel, g1((long)B * d.img_len * D), dim3(256), 0, c.s, img_c, h->img_pos, (void*)(c.ws + c.w.img_c), B, d.img_len, D, dt);
   CK(vt_check_launch());
   CK(cache_cond(c));
   CK(embed(c, t_is_scalar ? nullptr : t_dev, t_host, h->t_w1, h->t_b1, h->t_w2, h->t_b2, c.w.t_emb));
@@ -595,11 +608,11 @@ int vt_rdt_forward(vt_rdt_t h, const void* x_tokens, const float* freq, const fl
   // x_tokens is [B][horizon+1][D]: the state token, then the horizon action tokens
   const long xbs = (long)(d.horizon + 1) * D;
   hipLaunchKernelGGL(assemble_x_kernel, g1((long)B * N * D), dim3(256), 0, c.s, (float*)(c.ws + c.w.x), (const void*)(c.ws + c.w.t_emb), t_is_scalar,
-                     (const void*)(c.ws + c.w.freq_emb), x_tokens, xbs, (const void*)((const char*)x_tokens + (size_t)D * c.a), xbs, h->x_pos, B, N, D, bf);
+                     (const void*)(c.ws + c.w.freq_emb), x_tokens, xbs, (const void*)((const char*)x_tokens + (size_t)D * c.a), xbs, h->x_pos, B, N, D, dt);
   CK(vt_check_launch());
   CK(run_blocks(c, lang_mask));
   hipLaunchKernelGGL(take_actions_kernel, g1((long)B * d.horizon * d.out_dim), dim3(256), 0, c.s, (const void*)(c.ws + c.w.out_tok), out, B, N, d.horizon,
-                     d.out_dim, bf);
+                     d.out_dim, is16(dt) ? 1 : 0);
   return vt_check_launch();
 }
 
@@ -614,7 +627,8 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
   if (!lang_tokens || !img_tokens || !state_tokens || !action_mask || !ctrl_freqs || !x_init || !timesteps || !coef || !out || n_steps < 1)
     return vt_fail(VT_ERR_ARG, "vt_rdt_sample: null argument");
   const vt_rdt_desc& d = h->d;
-  const int D = d.hidden, N = d.horizon + 3, Hh = d.horizon, S = d.state_dim, bf = d.adt == VT_BF16, a = c.a;
+  const int D = d.hidden, N = d.horizon + 3, Hh = d.horizon, S = d.state_dim, dt = d.adt, a = c.a;
+  const bool bf = is16(dt);                       // a 16-bit mode (bf16 or IEEE fp16 activations)
   if (d.out_dim != S) return vt_fail(VT_ERR_ARG, "vt_rdt_sample: action_dim must equal state_token_dim");
   hipStream_t s = c.s;
   if (hipMemsetAsync(c.ws + c.w.sk_cnt, 0, RDT_SK_CNT * sizeof(int), s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "ticket counters");
@@ -626,38 +640,40 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
     CK(vt_k_place_cols(action_mask, d.adt, S, c.ws + c.w.sa_in, d.adt, 2 * S, S, B, S, s));
     CK(run_adaptor(c, h->state, c.ws + c.w.sa_in, 1, B, c.ws + c.w.state_tok, nullptr, c.ws + c.w.sa_tmpA, c.ws + c.w.sa_tmpB));
   } else {          // conditional_sample: lang/img/state tokens are already [.., hidden] (rdt_runner.py:122-134)
-    hipLaunchKernelGGL(add_pos_kernel, g1((long)B * L * D), dim3(256), 0, s, lang_tokens, h->lang_pos, (void*)(c.ws + c.w.lang_c), B, L, D, bf);
-    hipLaunchKernelGGL(add_pos_kernel, g1((long)B * d.img_len * D), dim3(256), 0, s, img_tokens, h->img_pos, (void*)(c.ws + c.w.img_c), B, d.img_len, D, bf);
+    hipLaunchKernelGGL(add_pos_kernel, g1((long)B * L * D), dim3(256), 0, s, lang_tokens, h->lang_pos, (void*)(c.ws + c.w.lang_c), B, L, D, dt);
+    hipLaunchKernelGGL(add_pos_kernel, g1((long)B * d.img_len * D), dim3(256), 0, s, img_tokens, h->img_pos, (void*)(c.ws + c.w.img_c), B, d.img_len, D, dt);
     CK(vt_check_launch());
     if (hipMemcpyAsync(c.ws + c.w.state_tok, state_tokens, (size_t)B * D * a, hipMemcpyDeviceToDevice, s) != hipSuccess) return vt_fail(VT_ERR_LAUNCH, "state copy");
   }
   CK(cache_cond(c));
   CK(embed(c, ctrl_freqs, 0.f, h->f_w1, h->f_b1, h->f_w2, h->f_b2, c.w.freq_emb));
   const long n = (long)B * Hh * S;
-  hipLaunchKernelGGL(take_xinit_kernel, g1(n), dim3(256), 0, s, x_init, (float*)(c.ws + c.w.noisy), n, bf);
+  // the start noise on the grid of the I/O dtype (the reference draws it in its dtype, rdt_runner.py:137-139): bf16 unless the handle says otherwise
+  hipLaunchKernelGGL(take_xinit_kernel, g1(n), dim3(256), 0, s, x_init, (float*)(c.ws + c.w.noisy), n, bf ? h->io_dt : VT_F32);
   CK(vt_check_launch());
   char* x0_cur = c.ws + c.w.x0_cur;
   char* x0_prev = c.ws + c.w.x0_prev;
   // 16-bit mode with the fp32 solver state (the default, vt_rdt_set_state_precision): fp32 final projection / x0 buffers, no per-step rounding of the state
   const int st32 = bf && h->state_f32;
-  const int x0_bf = bf && !st32;
+  const int x0_dt = (bf && !st32) ? dt : VT_F32;                  // storage type of out_tok / the x0 buffers
+  const int round_dt = (bf && !st32) ? h->io_dt : VT_F32;         // per-step rounding of the state (the reference's dtype)
   c.out_f32 = st32;
   for (int k = 0; k < n_steps; ++k) {
-    hipLaunchKernelGGL(build_sa_in_kernel, g1((long)B * Hh * 2 * S), dim3(256), 0, s, (const float*)(c.ws + c.w.noisy), action_mask, (void*)(c.ws + c.w.sa_in), B, Hh, S, bf);
+    hipLaunchKernelGGL(build_sa_in_kernel, g1((long)B * Hh * 2 * S), dim3(256), 0, s, (const float*)(c.ws + c.w.noisy), action_mask, (void*)(c.ws + c.w.sa_in), B, Hh, S, dt);
     CK(vt_check_launch());
     CK(run_adaptor(c, h->state, c.ws + c.w.sa_in, Hh, B, c.ws + c.w.sa_tmpA, nullptr, c.ws + c.w.tmpA, c.ws + c.w.tmpB));   // action tokens -> sa_tmpA
     CK(embed(c, nullptr, timesteps[k], h->t_w1, h->t_b1, h->t_w2, h->t_b2, c.w.t_emb, h->t_w1p, h->t_w2p));
     hipLaunchKernelGGL(assemble_x_kernel, g1((long)B * N * D), dim3(256), 0, s, (float*)(c.ws + c.w.x), (const void*)(c.ws + c.w.t_emb), 1,
                        (const void*)(c.ws + c.w.freq_emb), (const void*)(c.ws + c.w.state_tok), (long)D, (const void*)(c.ws + c.w.sa_tmpA), (long)Hh * D,
-                       h->x_pos, B, N, D, bf);
+                       h->x_pos, B, N, D, dt);
     CK(vt_check_launch());
     CK(run_blocks(c, lang_mask));
-    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, x0_bf);
+    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, x0_dt != VT_F32 ? 1 : 0);
     CK(vt_check_launch());
     const float* cf = coef + 5 * k;
     const bool last = k == n_steps - 1;
     hipLaunchKernelGGL(dpm_update_kernel, g1(n), dim3(256), 0, s, (float*)(c.ws + c.w.noisy), (const void*)x0_cur, (const void*)(cf[2] != 0.f ? x0_prev : nullptr), cf[0], cf[1],
-                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, x0_bf, x0_bf, bf, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
+                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, x0_dt, round_dt, dt, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
     CK(vt_check_launch());
     char* t = x0_cur; x0_cur = x0_prev; x0_prev = t;
   }

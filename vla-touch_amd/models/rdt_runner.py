@@ -72,8 +72,17 @@ def resolve_rms_mode(explicit: Optional[str], rdt_cfg: dict) -> str:
 class RDTRunner:
     def __init__(self, *, action_dim, pred_horizon, config, lang_token_dim, img_token_dim, state_token_dim, max_lang_cond_len,
                  img_cond_len, lang_pos_embed_config=None, img_pos_embed_config=None, dtype=torch.bfloat16, device="cuda",
-                 rms_mode: Optional[str] = None, init_weights: bool = True, solver_state: Optional[str] = None):
+                 rms_mode: Optional[str] = None, init_weights: bool = True, solver_state: Optional[str] = None, compute_dtype=None):
         hidden_size = config['rdt']['hidden_size']
+        # compute_dtype (extension): the engine's 16-bit activation / MFMA operand type for a bf16 model — torch.float16 (default: the bf16 weights convert
+        # exactly, same width and MFMA rate, 3 more mantissa bits: |chunk - fp32 reference| 1e-2 -> 1.2e-3 at RDT-1B) or torch.bfloat16
+        # (the reference's own execution dtype, rounding after every op).  config['rdt']['compute_dtype'] / VLATOUCH_RDT_COMPUTE = "f16" | "bf16".
+        cd = compute_dtype or config.get('rdt', {}).get('compute_dtype') or os.environ.get("VLATOUCH_RDT_COMPUTE", "f16")
+        if isinstance(cd, str):
+            if cd not in ("f16", "fp16", "float16", "bf16", "bfloat16"):
+                raise ValueError(f"compute_dtype must be 'f16' or 'bf16', got {cd!r}")
+            cd = torch.float16 if cd in ("f16", "fp16", "float16") else torch.bfloat16
+        self.compute_dtype = cd if dtype == torch.bfloat16 else dtype       # fp32 (and true fp16) models compute in their own dtype
         # precision of the sampler's state between network evaluations in the 16-bit mode (extension; RdtEngine): "fp32" (default) or the reference's "bf16"
         self.solver_state = solver_state or config.get('rdt', {}).get('solver_state') or os.environ.get("VLATOUCH_RDT_SOLVER_STATE", "fp32")
         self.config = config
@@ -164,7 +173,7 @@ class RDTRunner:
                 horizon=self.pred_horizon, action_dim=self.action_dim, lang_token_dim=self.lang_token_dim, img_token_dim=self.img_token_dim,
                 state_token_dim=self.state_token_dim, max_lang_cond_len=self.max_lang_cond_len, img_cond_len=self.img_cond_len,
                 lang_adaptor=self.config['lang_adaptor'], img_adaptor=self.config['img_adaptor'], state_adaptor=self.config['state_adaptor'],
-                dtype=self.dtype, rms_mode=self.rms_mode, solver_state=self.solver_state, device=self.device)
+                dtype=self.compute_dtype, io_dtype=self.dtype, rms_mode=self.rms_mode, solver_state=self.solver_state, device=self.device)
             self._engine_key = key
         return self._engine
 

@@ -165,6 +165,7 @@ SIGNATURES = {
     "vt_rdt_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_rdt_set_score_bounds": (_I, [_P, _P, _I]),
     "vt_rdt_set_state_precision": (_I, [_P, _I]),
+    "vt_rdt_set_io_dtype": (_I, [_P, _I]),
     "vt_rdt_packed_bytes": (_Z, [_P]),
     "vt_rdt_set_packed": (_I, [_P, _P, _P]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),

@@ -29,13 +29,18 @@ class RdtEngine:
     def __init__(self, sd: SD, *, hidden: int, depth: int, heads: int, horizon: int, action_dim: int, lang_token_dim: int,
                  img_token_dim: int, state_token_dim: int, max_lang_cond_len: int, img_cond_len: int,
                  lang_adaptor: str = "mlp2x_gelu", img_adaptor: str = "mlp2x_gelu", state_adaptor: str = "mlp3x_gelu",
-                 dtype: torch.dtype = torch.bfloat16, rms_mode: str = "meansq", solver_state: str = "fp32", device="cuda"):
-        """solver_state (16-bit mode only): "fp32" (default) keeps the DPM-Solver++ state, the x0 predictions and the final projection in fp32 between
+                 dtype: torch.dtype = torch.bfloat16, rms_mode: str = "meansq", solver_state: str = "fp32", io_dtype: Optional[torch.dtype] = None,
+                 device="cuda"):
+        """dtype = the engine's storage / MFMA operand type (fp32, bf16, or IEEE fp16).  io_dtype = the MODEL's dtype when it differs: a bf16 checkpoint
+        evaluated with fp16 activations (dtype=torch.float16, io_dtype=torch.bfloat16: the bf16 weights convert exactly, same width and MFMA rate, 8x
+        smaller activation rounding) still rounds its start noise / returns its result on the bf16 grid.
+        solver_state (16-bit mode only): "fp32" (default) keeps the DPM-Solver++ state, the x0 predictions and the final projection in fp32 between
         network evaluations — closer to the fp32 reference; "bf16" reproduces the reference's bf16 rounding points (rdt_runner.py:137-139,160)."""
         self.device = L.require_gpu(device)
         if solver_state not in ("fp32", "bf16"):
             raise ValueError(f"solver_state must be 'fp32' or 'bf16', got {solver_state!r}")
         self.solver_state = solver_state
+        self.io_dtype = io_dtype or dtype
         if hidden // heads != 64:
             raise L.VtError("RdtEngine: head_dim must be 64")
         self.dtype = dtype
@@ -83,6 +88,8 @@ class RdtEngine:
         self._h = C.c_void_p()
         L.check(lib.vt_rdt_create(C.byref(d), L.ptr_array(W), len(W), C.byref(self._h)), "vt_rdt_create")
         L.check(lib.vt_rdt_set_state_precision(self._h, int(solver_state == "fp32")), "vt_rdt_set_state_precision")
+        if dtype != torch.float32 and self.io_dtype != torch.float32:
+            L.check(lib.vt_rdt_set_io_dtype(self._h, L.dt_code(self.io_dtype)), "vt_rdt_set_io_dtype")
         self._ws = _Workspace(dev)
         # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
         self._depth, self._rms_mode = depth, rms_mode
@@ -98,7 +105,7 @@ class RdtEngine:
         (+2 %: the normed q / k are stored in bf16): lets the cached cross-attention drop its running maximum.  The variance form has no
         such bound -> 0 (online softmax).  Weight order per block: see csrc/vt_rdt.hip (cq_norm at +12, ck_norm at +13)."""
         bounds = (C.c_float * self._depth)()
-        if self._rms_mode == "meansq" and self.dtype == torch.bfloat16:
+        if self._rms_mode == "meansq" and self.dtype in (torch.bfloat16, torch.float16):
             for i in range(self._depth):
                 base = 11 + 21 * i
                 wq, wk = self._weights[base + 12], self._weights[base + 13]
@@ -207,4 +214,4 @@ class RdtEngine:
         L.check(L.lib().vt_rdt_sample(self._h, L.ptr(lang_tokens), L.ptr(mask), L.ptr(img_tokens), L.ptr(state_tokens), L.ptr(action_mask),
                                       L.ptr(ctrl_freqs), L.ptr(x_init), len(ts), ts_c, coef_c, int(prediction_type == "sample"), int(adapted), L.ptr(out), B, Llang,
                                       L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)), "vt_rdt_sample")
-        return out if return_fp32 else out.to(dt)
+        return out if return_fp32 else out.to(self.io_dtype)
