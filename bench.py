@@ -71,6 +71,9 @@ def parse():
     ap.add_argument("--force-dim", type=int, default=3,
                     help="width of the tactile vector m_t fed to the observation MLP (reference default 3 = the marker tracker's force estimate, "
                          "bridge_controller.py:25; BASELINE.json's synthetic workload names a 64-d tactile vector: --force-dim 64)")
+    ap.add_argument("--alt-compute-steps", type=int, default=12,
+                    help="steps of the extra timed pass with the OTHER 16-bit activation type of RDT-1B (reported as `alt_rdt_compute`: a second runner on the "
+                         "same weights, its own graphs; workloads with an RDT chunk only; 0 = skip)")
     ap.add_argument("--latency-steps", type=int, default=6,
                     help="steps of the extra ONE-batch-at-a-time pass run after the timed region (reported as `latency_mode`; 0 = skip)")
     return ap.parse_args()
@@ -241,10 +244,13 @@ def main():
             tok_bufs = [torch.empty(6 * B, 729, 1152, dtype=rdt.compute_dtype, device=dev) for _ in range(n_streams)]
     setup_s = time.time() - t0
 
+    ctx = {"rdt": rdt, "rins": rins if rdt is not None else None}       # which RDT runner the step drives (the alt-compute pass swaps it)
+
     def step(slot=0):
         out_holder, noise_buf = out_holders[slot], noise_bufs[slot]
         inp = inps[slot]
-        rin = rins[slot] if rdt is not None else None
+        rdt = ctx["rdt"]
+        rin = ctx["rins"][slot] if rdt is not None else None
         lstm_in = lstm_ins[slot] if lstm is not None else None
         sig_px = sig_pxs[slot] if sig is not None else None
         if args.workload == "lstm":
@@ -374,12 +380,59 @@ def main():
             lib.vt_prof_enable(0)
             prof[mode] = (ms.value, fl.value, by.value, n.value)
 
+    # ---- the same timed pattern with the other 16-bit activation type of RDT-1B (f16 <-> bf16): a second runner on the SAME weights, its own
+    #      workspaces and graphs; reported beside the headline so that the record carries what the choice of the default costs / buys
+    alt_elapsed = None
+    if rdt is not None and args.precision == "bf16" and args.alt_compute_steps > 0 and args.workload in ("full", "rdt"):
+        from models.rdt_runner import RDTRunner as _RR
+        alt_mode = "bf16" if args.rdt_compute == "f16" else "f16"
+        rdt_alt = _RR(action_dim=128, pred_horizon=64, config=cfg, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128, max_lang_cond_len=1024,
+                      img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False, compute_dtype=alt_mode)
+        rdt_alt.load_state_dict(rdt.state_dict(), assign=True)
+        alt_in = rdt_alt.compute_dtype
+        rins_alt = [{k: (v.to(alt_in) if v.is_floating_point() and k != "freq" else v) for k, v in r_.items()} for r_ in rins]
+        ctx["rdt"], ctx["rins"] = rdt_alt, rins_alt
+        graphs_alt = []
+        for si, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                step(si)
+                st.synchronize()
+                g_ = None
+                if graph is not None:
+                    g_ = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_, stream=st):
+                        step(si)
+                    g_.replay()
+                    st.synchronize()
+                graphs_alt.append(g_)
+
+        def run_alt(i):
+            si = i % n_streams
+            with torch.cuda.stream(streams[si]):
+                if graphs_alt[si] is not None:
+                    graphs_alt[si].replay()
+                else:
+                    step(si)
+        for i in range(n_streams * 2):
+            run_alt(i)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.alt_compute_steps):
+            run_alt(i)
+        barrier()
+        alt_elapsed = time.perf_counter() - t1
+        ctx["rdt"], ctx["rins"] = rdt, rins
+        del graphs_alt, rins_alt, rdt_alt
+        torch.cuda.empty_cache()
+
     if dist is not None:
-        tt = torch.tensor([elapsed, lat_elapsed or 0.0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
+        tt = torch.tensor([elapsed, lat_elapsed or 0.0, alt_elapsed or 0.0], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0].item())
         if lat_elapsed is not None:
             lat_elapsed = float(tt[1].item())
+        if alt_elapsed is not None:
+            alt_elapsed = float(tt[2].item())
     total_chunks = B * world * args.steps * (8 if args.workload == "marker" else 1)
     value = total_chunks / elapsed
 
@@ -437,6 +490,11 @@ def main():
     elif n_streams == 1:
         res["latency_mode"] = {"chunks_per_s": res["value"], "ms_per_step": res["ms_per_step"], "steps": args.steps, "batches_in_flight": 1,
                                "note": "the timed region itself (one batch in flight)"}
+    if alt_elapsed is not None:
+        res["alt_rdt_compute"] = {"rdt_compute": "bf16" if args.rdt_compute == "f16" else "f16", "chunks_per_s": round(B * world * args.alt_compute_steps / alt_elapsed, 2),
+                                  "ms_per_step": round(1000 * alt_elapsed / args.alt_compute_steps, 4), "steps": args.alt_compute_steps, "batches_in_flight": n_streams,
+                                  "note": "the same step with the other 16-bit activation type of RDT-1B (bf16 = the reference's execution dtype: |chunk - fp32 oracle| "
+                                          "~8e-3..1.1e-2; f16 = the default: ~1e-3), same weights, same box, timed right after the headline"}
     # end-to-end matrix-pipe fraction: SURVEY 8(d)'s algorithmic GFLOP per chunk (2 MAC, cached condition K/V, no recompute credit) x chunks / wall time
     gf_chunk = {"full": (1030.0 + 168.0 * args.rdt_steps + 57.0) + 99.3, "rdt": 1030.0 + 168.0 * args.rdt_steps + 57.0, "pi_refine": 99.3, "dino_mlp": 92.6}.get(args.workload)
     if gf_chunk is not None and args.dino == "base" and args.horizon == 16:

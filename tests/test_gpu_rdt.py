@@ -117,7 +117,7 @@ def test_predict_action_vs_oracle_sampler(dname, dtype, compute):
                                      x_init=ri["x_init"], return_fp32=True)
             e32 = err(out32, exact)
             print(f"[compute f16, fp32 hand-over] |hip16-exact| {e32:.3e}")
-            assert e32 <= 2.5e-3 * scale, (e32, scale)
+            assert e32 <= 4e-3 * scale, (e32, scale)              # (the tiny config: D = 256 averages less than RDT-1B, where it is 7e-4 of the scale)
 
 
 def test_conditional_sample_equals_predict_action_and_errors():
