@@ -13,6 +13,8 @@ run full_streams2_n1 --streams 2 --no-cpu-baseline
 run full_streams1_n1 --streams 1 --no-cpu-baseline
 run full_streams4_n1 --streams 4 --no-cpu-baseline
 run full_rmsvar_n1 --rms-mode var --no-cpu-baseline
+run full_bf16act_n1 --rdt-compute bf16 --no-cpu-baseline
+run full_tactile64_n1 --force-dim 64 --no-cpu-baseline
 run pi_refine_n1 --workload pi_refine --no-cpu-baseline
 run pi_refine_streams1_n1 --workload pi_refine --no-cpu-baseline --streams 1
 run dino_mlp_n1 --workload dino_mlp --no-cpu-baseline
