@@ -48,4 +48,8 @@ struct VtGemmParams {
   //       rs_mode 2 (unbiased variance, x not centred, <= 1.0.8): rstd = rsqrt((Q - S^2 / K) / (K - 1) + rs_eps)
   void* xn_out; long xn_ld; const float* xn_gain; float* xn_part;
   const float* rs_part; int rs_n; float rs_inv_k, rs_eps; int rs_mode;
+  // prefetch hint (vt_gemm_pw.hip): pf_bytes of memory at pf_ptr — the NEXT launch's frozen weights — are touched (one dword per 64 bytes, dealt over the
+  // blocks) at the top of this launch's epilogue, so that they stream HBM -> Infinity Cache under its store drain and the kernel boundary instead of at the
+  // head of the next launch's k-loop.  Null = none.  Results do not depend on it.
+  const void* pf_ptr; size_t pf_bytes;
 };

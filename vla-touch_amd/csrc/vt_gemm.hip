@@ -364,6 +364,7 @@ int vt_gemm_launch(const VtGemmParams& p, hipStream_t s) {
   if (p.taps && (p.cin % epc || p.K != p.taps * p.cin)) return VT_ERR_ARG;
   if (p.splitk < 1 || p.groups < 1) return VT_ERR_ARG;
   if (p.splitk > 1 && p.c_dtype != VT_F32) return VT_ERR_ARG;
+  if (p.pf_ptr && p.pf_bytes >= (1ul << 31)) return VT_ERR_ARG;      // prefetch hint: 32-bit byte arithmetic in the kernel
   if (p.xn_out || p.rs_part) {        // fused RMSNorm hand-off: only the weights-in-registers tile implements it, and the caller has checked that it takes this shape
     if (p.groups != 1 || (p.xn_out && (!p.xn_gain || !p.xn_part || p.c_dtype != VT_F32 || !p.residual || p.act != VT_ACT_NONE || p.hn_w0 || p.hn_w1 || p.xn_ld % 4)) ||
         (p.rs_part && (p.rs_n < 4 || p.rs_n > 32 || p.rs_n % 4)) || !vt_gemm_fast_eligible(p) || !vt_gemm_pw_eligible(p))

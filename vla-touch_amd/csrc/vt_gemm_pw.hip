@@ -266,6 +266,37 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
       }
     }
   }
+  // the epilogue's parameter rows (bias, column scale, head-norm gains, the hand-off's norm gains) are requested HERE, with the residual rows and ahead of
+  // the prefetch hint below: vmcnt retires in order, so a load issued behind the hint's HBM reads would wait for them
+  const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
+  const float* hw = nullptr;
+  if (p.hn_w0 && ncol0 < p.hn_c0_end) hw = p.hn_w0;
+  else if (p.hn_w1 && ncol0 >= p.hn_c0_end && ncol0 < p.hn_c1_end) hw = p.hn_w1;
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 b4 = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : zero4;
+  const float4 cs4 = (p.colscale && col_ok) ? *reinterpret_cast<const float4*>(p.colscale + n) : one4;
+  const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
+  float4 g4 = zero4;
+  if constexpr (FUSE == 1) { if (col_ok && p.xn_gain) g4 = *reinterpret_cast<const float4*>(p.xn_gain + n); }
+  __builtin_amdgcn_sched_barrier(0);
+  // ---------------- prefetch hint: this block's share of the NEXT launch's weights, one dword per 64 bytes, fire and forget (retired by the wait the hardware
+  // performs before s_endpgm; the values are never used).  Behind every load the epilogue itself consumes: the stream HBM -> Infinity Cache runs under the LDS
+  // exchange, the store drain and the kernel boundary.  No ordinary load may follow it in this kernel.
+  constexpr int PFN = 8;
+  unsigned pfv[PFN];
+#pragma unroll
+  for (int i = 0; i < PFN; ++i) pfv[i] = 0;
+  if (p.pf_ptr) {
+    const unsigned nbytes = (unsigned)p.pf_bytes;                                                // (the launcher admits hints below 2 GiB)
+    const unsigned share = ((nbytes + (unsigned)total_tiles - 1u) / (unsigned)total_tiles + 63u) & ~63u;   // bytes per block, whole 64-byte units
+    const unsigned b0 = blockIdx.x * share;
+    const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.pf_ptr + b0), 0,
+                                                                        b0 < nbytes ? (int)min(share, nbytes - b0) : 0, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < PFN; ++i)
+      if ((unsigned)i * 16384u < share) pfv[i] = __builtin_amdgcn_raw_buffer_load_b32(rsP, (i * 256 + tid) * 64, 0, 0);      // out-of-range lanes: the hardware returns 0
+  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < TMW; ++j) {
     const int m = j * 32 + l31;
@@ -278,14 +309,6 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
     }
   }
   __syncthreads();
-  const float* bias = p.bias ? p.bias + (long)grp * p.bias_gs : nullptr;
-  const float* hw = nullptr;
-  if (p.hn_w0 && ncol0 < p.hn_c0_end) hw = p.hn_w0;
-  else if (p.hn_w1 && ncol0 >= p.hn_c0_end && ncol0 < p.hn_c1_end) hw = p.hn_w1;
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f), one4 = make_float4(1.f, 1.f, 1.f, 1.f);
-  const float4 b4 = (bias && col_ok) ? *reinterpret_cast<const float4*>(bias + n) : zero4;
-  const float4 cs4 = (p.colscale && col_ok) ? *reinterpret_cast<const float4*>(p.colscale + n) : one4;
-  const float4 hw4 = hw ? *reinterpret_cast<const float4*>(hw + c4 * 4) : one4;
   if (p.act != VT_ACT_NONE) {
 #pragma unroll 2
     for (int it = 0; it < BM / 8; ++it) {
@@ -297,7 +320,6 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
     // producer of a fused RMSNorm: C = residual + colscale * (product + bias) as below, plus the 16-bit copy C * gain the next Linear reads as its
     // A operand and the (sum of squares, sum) of this row over the wave's 64 columns (all 16 lanes of a row segment take part in the reductions)
     if constexpr (PRE && FUSE == 1) {
-      const float4 g4 = col_ok ? *reinterpret_cast<const float4*>(p.xn_gain + n) : zero4;
       T16* Xn = reinterpret_cast<T16*>(p.xn_out);
       const int pcol = 2 * tn + half, pn = 2 * tiles_n;
 #pragma unroll
@@ -336,6 +358,8 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
       vt_epi_segment<TC, 0, false>(p, x, b4, cs4, hw, hw4, Cg, Rg, m0 + row, n, ncol0, col_ok);
     }
   }
+#pragma unroll
+  for (int i = 0; i < PFN; ++i) asm volatile("" :: "v"(pfv[i]));       // (the prefetch loads are not dead code)
 }
 
 // W [N][K] row-major (ldw) -> fragment order: out[((n/32 * K/16 + k/16) * 64 + (k%16)/8 * 32 + n%32) * 8 + k%8]; one thread per 16-byte chunk

@@ -235,6 +235,7 @@ RWs rcarve(const vt_rdt_s* h, int B, int L) {
 }
 
 struct RCtx { const vt_rdt_s* h; int B, L; char* ws; RWs w; hipStream_t s; int a;
+              const void* pf_next = nullptr; size_t pf_bytes = 0;   // prefetch hint for the next rgemm on the weights-in-registers tile: the weights of the Linear after it
               bool out_f32 = false;       // the final projection writes out_tok in fp32 (vt_rdt_sample with the fp32 solver state)
               bool fuse_norm = false;     // residual Linears hand the RMSNorm that follows them to the next Linear (vt_gemm.h, xn_out / rs_part)
               bool rs_pending = false; }; // c.w.xn holds x * gain, un-normalised: the next Linear applies rstd from c.w.rs_part
@@ -285,8 +286,12 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
         c.rs_pending = true;
       }
     }
+    static const bool pf_on = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return !e || atoi(e) != 0; }();
+    if (pf_on && c.pf_next && p.Wp && vt_gemm_fast_eligible(p) && vt_gemm_pw_eligible(p)) { p.pf_ptr = c.pf_next; p.pf_bytes = c.pf_bytes; }
+    c.pf_next = nullptr;
     return vt_wrap(vt_gemm_launch(p, c.s), what);
   }
+  c.pf_next = nullptr;
   VtGemmParams q = p;
   q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
   q.bias = nullptr; q.act = VT_ACT_NONE; q.colscale = nullptr; q.residual = nullptr;
@@ -459,6 +464,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
       CK(take_rstd(c, p, b.norm1));
       bool fused = fuse_headnorm(p, b.qn, D, b.kn, 2 * D, d.rms_mode);   // q_norm | k_norm | (v untouched)
       bool folded = false;
+      c.pf_next = b.proj_wp; c.pf_bytes = (size_t)D * D * a;
       CK(rgemm(c, p, "rdt qkv", fused ? nullptr : b.qn, D, b.kn, 2 * D, &folded));
       fused = fused || folded;
       if (!fused) {
@@ -468,6 +474,7 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
     CK(attn(c, c.ws + c.w.qkv, 3 * D, c.ws + c.w.qkv + (size_t)D * a, c.ws + c.w.qkv + (size_t)2 * D * a, 3 * D, N, N, nullptr, c.ws + c.w.att));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.proj_w, d.cdt, D, b.proj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.proj_wp);
       p.residual = x; p.ldr = D;
+      c.pf_next = b.cq_wp; c.pf_bytes = (size_t)D * D * a;
       CK(rgemm(c, p, "rdt proj", nullptr, 0, nullptr, 0, nullptr, b.norm2, &xn_ready)); }
     // --- cross attention against the cached condition K/V
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm2, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
@@ -476,21 +483,26 @@ int run_blocks(RCtx& c, const uint8_t* lang_mask) {
       CK(take_rstd(c, p, b.norm2));
       bool fused = fuse_headnorm(p, b.cqn, D, nullptr, D, d.rms_mode);
       bool folded = false;
+      c.pf_next = b.cproj_wp; c.pf_bytes = (size_t)D * D * a;
       CK(rgemm(c, p, "rdt cross q", fused ? nullptr : b.cqn, D, nullptr, D, &folded));
       fused = fused || folded;
       if (!fused) CK(vt_k_headnorm(c.ws + c.w.q, d.adt, D, d.heads, M, b.cqn, 1e-6f, d.rms_mode, c.s)); }
     CK(cross_attn(c, l, lang_mask, N));
     { VtGemmParams p = lin(c.ws + c.w.att, d.adt, D, b.cproj_w, d.cdt, D, b.cproj_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.cproj_wp);
       p.residual = x; p.ldr = D;
+      c.pf_next = b.fc1_wp; c.pf_bytes = (size_t)D * D * a;
       CK(rgemm(c, p, "rdt cross proj", nullptr, 0, nullptr, 0, nullptr, b.norm3, &xn_ready)); }
     // --- FFN (hidden = D, tanh-GELU)
     if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, b.norm3, nullptr, M, D, 1e-6f, d.rms_mode, c.s));
     xn_ready = false;
     { VtGemmParams p = lin(c.ws + c.w.xn, d.adt, D, b.fc1_w, d.cdt, D, b.fc1_b, c.ws + c.w.hid, d.adt, D, M, D, D, VT_ACT_GELU_TANH, b.fc1_wp);
       CK(take_rstd(c, p, b.norm3));
+      c.pf_next = b.fc2_wp; c.pf_bytes = (size_t)D * D * a;
       CK(rgemm(c, p, "rdt fc1")); }
     { VtGemmParams p = lin(c.ws + c.w.hid, d.adt, D, b.fc2_w, d.cdt, D, b.fc2_b, x, VT_F32, D, M, D, D, VT_ACT_NONE, b.fc2_wp);
       p.residual = x; p.ldr = D;
+      if (l + 1 < d.depth) { c.pf_next = c.h->blk[l + 1].qkv_wp; c.pf_bytes = (size_t)3 * D * D * a; }
+      else { c.pf_next = c.h->ffc1_wp; c.pf_bytes = (size_t)D * D * a; }
       CK(rgemm(c, p, "rdt fc2", nullptr, 0, nullptr, 0, nullptr, norm_after, &xn_ready, l + 1 < d.depth)); }   // the final layer's fc1 is not a consumer of the hand-off
   }
   if (!xn_ready) CK(vt_k_rownorm(x, VT_F32, D, c.ws + c.w.xn, d.adt, D, c.h->normf, nullptr, M, D, 1e-6f, d.rms_mode, c.s));

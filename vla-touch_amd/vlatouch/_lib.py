@@ -46,6 +46,7 @@ class GemmParams(C.Structure):
         # fused RMSNorm hand-off between two Linears (vt_gemm.h): producer side / consumer side
         ("xn_out", C.c_void_p), ("xn_ld", C.c_long), ("xn_gain", C.c_void_p), ("xn_part", C.c_void_p),
         ("rs_part", C.c_void_p), ("rs_n", C.c_int), ("rs_inv_k", C.c_float), ("rs_eps", C.c_float), ("rs_mode", C.c_int),
+        ("pf_ptr", C.c_void_p), ("pf_bytes", C.c_size_t),
     ]
 
 
