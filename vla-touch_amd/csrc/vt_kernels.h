@@ -65,11 +65,12 @@ int vt_k_groupnorm(const VtGnParams& p, hipStream_t s);
 // out = residual + colscale * act(sum of S fp32 split-K slabs [S][M][N] + bias); residual has the output dtype
 // x += sum of slabs + bias (fp32, in place), xn = rownorm(x) * w (+ b): a residual Linear and the norm that follows it (N <= 2048)
 int vt_k_slab_reduce_norm(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, float* x, long ldx, const float* w,
-                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s);
+                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s,
+                          const void* pf_ptr = nullptr, size_t pf_bytes = 0);   // pf_*: the next GEMM's weights, touched by 128 extra prefetch-only blocks
 // optional per-head (64 columns) RMSNorm after the bias: hn_w0 for columns [0, hn_c0), hn_w1 for [hn_c0, hn_c1) (then no act / residual use)
 int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
                      const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
-                     float hn_eps, int hn_mode, hipStream_t s);
+                     float hn_eps, int hn_mode, hipStream_t s, const void* pf_ptr = nullptr, size_t pf_bytes = 0);
 int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
 int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s);       // h[r][c] = silu(h[r][c]) * h[r][F + c], c < F, in place
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);

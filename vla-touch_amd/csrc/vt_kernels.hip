@@ -269,6 +269,17 @@ __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
   }
 }
 
+// Prefetch-only blocks of the slab-reduction launches (small-batch RDT path): blocks pf_block0 .. of the grid touch one dword per 64 bytes of the NEXT
+// GEMM's frozen weights and exit — the weights stream HBM -> Infinity Cache on CUs the reduction leaves idle (M = 67 rows use a quarter of the chip),
+// instead of at the head of the next launch.  Fire and forget: the hardware retires the loads before s_endpgm.
+constexpr int VT_PF_BLOCKS = 128;
+__device__ __forceinline__ void vt_prefetch_block(const void* pf_ptr, unsigned pf_bytes, int pb, int tid) {
+  unsigned tmp = 0;
+  for (unsigned off = (unsigned)(pb * 256 + tid) * 64u; off < pf_bytes; off += (unsigned)VT_PF_BLOCKS * 256u * 64u)
+    asm volatile("global_load_dword %0, %1, off" : "=v"(tmp) : "v"(reinterpret_cast<const char*>(pf_ptr) + off) : "memory");
+  asm volatile("" :: "v"(tmp));
+}
+
 // ------------------------------------------------------------------ split-K slab reduction + Linear epilogue (small-M GEMMs)
 // out[m, n..n+3] = residual + colscale * act(sum_s slab[s][m][n] + bias): the tail of a GEMM whose k range was split over
 // blocks because M alone gives too few tiles to hide a 2048-deep k-loop (RDT at batch 1-4: M = 67..268 rows).
@@ -277,7 +288,9 @@ __global__ __launch_bounds__(256) void gn_kernel(const VtGnParams p) {
 template <typename TO>
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int S, long slab_stride, int M, int N, const float* __restrict__ bias,
                                                           int act, const float* __restrict__ cs, const TO* __restrict__ R, long ldr, TO* __restrict__ out, long ldo,
-                                                          const float* __restrict__ hn_w0, const float* __restrict__ hn_w1, int hn_c0, int hn_c1, float hn_eps, int hn_mode) {
+                                                          const float* __restrict__ hn_w0, const float* __restrict__ hn_w1, int hn_c0, int hn_c1, float hn_eps, int hn_mode,
+                                                          const void* pf_ptr, unsigned pf_bytes, int pf_block0) {
+  if (pf_ptr && (int)blockIdx.x >= pf_block0) { vt_prefetch_block(pf_ptr, pf_bytes, blockIdx.x - pf_block0, threadIdx.x); return; }
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   const int n4 = N >> 2;
   const bool live = i < (long)M * n4;
@@ -325,7 +338,8 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 template <typename TN, int NV>
 __global__ __launch_bounds__(256) void slab_reduce_norm_kernel(const float* __restrict__ slabs, int S, long slab_stride, int N, const float* __restrict__ bias,
                                                                float* __restrict__ x, long ldx, const float* __restrict__ w, const float* __restrict__ b,
-                                                               float eps, int mode, TN* __restrict__ xn, long ldxn) {
+                                                               float eps, int mode, TN* __restrict__ xn, long ldxn, const void* pf_ptr, unsigned pf_bytes, int pf_block0) {
+  if (pf_ptr && (int)blockIdx.x >= pf_block0) { vt_prefetch_block(pf_ptr, pf_bytes, blockIdx.x - pf_block0, threadIdx.x); return; }
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, m = blockIdx.x;
   const int nv = N >> 2;
@@ -688,19 +702,25 @@ int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, cons
 
 int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, int act, const float* colscale,
                      const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
-                     float hn_eps, int hn_mode, hipStream_t s) {
+                     float hn_eps, int hn_mode, hipStream_t s, const void* pf_ptr, size_t pf_bytes) {
   if (S < 1 || (N & 3) || M <= 0 || (hn_w0 && (N & 63))) return VT_ERR_ARG;
   const long n = (long)M * (N >> 2);
-  DISPATCH_T(odt, TO, hipLaunchKernelGGL((slab_reduce_kernel<TO>), g1(n), dim3(256), 0, s, slabs, S, slab_stride, M, N, bias, act, colscale,
-                                         (const TO*)residual, ldr, (TO*)out, ldo, hn_w0, hn_w1, hn_c0, hn_c1, hn_eps, hn_mode))
+  if (pf_bytes >= (1ul << 31)) pf_ptr = nullptr;
+  dim3 grid = g1(n);
+  const int pf_block0 = (int)grid.x;
+  if (pf_ptr) grid.x += VT_PF_BLOCKS;
+  DISPATCH_T(odt, TO, hipLaunchKernelGGL((slab_reduce_kernel<TO>), grid, dim3(256), 0, s, slabs, S, slab_stride, M, N, bias, act, colscale,
+                                         (const TO*)residual, ldr, (TO*)out, ldo, hn_w0, hn_w1, hn_c0, hn_c1, hn_eps, hn_mode, pf_ptr, (unsigned)pf_bytes, pf_block0))
   return vt_check_launch();
 }
 
 int vt_k_slab_reduce_norm(const float* slabs, int S, long slab_stride, int M, int N, const float* bias, float* x, long ldx, const float* w,
-                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s) {
+                          const float* b, float eps, int mode, void* xn, int xn_dt, long ldxn, hipStream_t s, const void* pf_ptr, size_t pf_bytes) {
   if (S < 1 || (N & 3) || N > 2048 || M <= 0 || (ldx & 3) || (ldxn & 3)) return VT_ERR_ARG;
-  DISPATCH_T(xn_dt, TN, hipLaunchKernelGGL((slab_reduce_norm_kernel<TN, 2>), dim3(M), dim3(256), 0, s, slabs, S, slab_stride, N, bias, x, ldx, w, b, eps,
-                                           mode, (TN*)xn, ldxn))
+  if (pf_bytes >= (1ul << 31)) pf_ptr = nullptr;
+  const int grid = M + (pf_ptr ? VT_PF_BLOCKS : 0);
+  DISPATCH_T(xn_dt, TN, hipLaunchKernelGGL((slab_reduce_norm_kernel<TN, 2>), dim3(grid), dim3(256), 0, s, slabs, S, slab_stride, N, bias, x, ldx, w, b, eps,
+                                           mode, (TN*)xn, ldxn, pf_ptr, (unsigned)pf_bytes, M))
   return vt_check_launch();
 }
 

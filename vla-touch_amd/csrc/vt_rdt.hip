@@ -291,6 +291,10 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
     c.pf_next = nullptr;
     return vt_wrap(vt_gemm_launch(p, c.s), what);
   }
+  // split path (small batch): the slab reduction behind the GEMM carries the hint, on extra blocks of its own launch
+  static const bool pf_small = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return !e || atoi(e) != 0; }();
+  const void* pfp = pf_small ? c.pf_next : nullptr;
+  const size_t pfb = c.pf_bytes;
   c.pf_next = nullptr;
   VtGemmParams q = p;
   q.C = c.ws + c.w.slab; q.c_dtype = VT_F32; q.ldc = p.N; q.splitk = S; q.c_slab = (long)p.M * p.N;
@@ -300,12 +304,12 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
       !p.colscale && p.ldc == p.N && p.ldr == p.N) {
     *xn_done = true;
     return vt_wrap(vt_k_slab_reduce_norm((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, (float*)p.C, p.ldc, next_norm, nullptr, 1e-6f,
-                                         c.h->d.rms_mode, c.ws + c.w.xn, c.h->d.adt, p.N, c.s), what);
+                                         c.h->d.rms_mode, c.ws + c.w.xn, c.h->d.adt, p.N, c.s, pfp, pfb), what);
   }
   const bool hn = hn_w0 && (p.N % 64) == 0;
   if (hn && hn_done) *hn_done = true;
   return vt_wrap(vt_k_slab_reduce((const float*)(c.ws + c.w.slab), S, q.c_slab, p.M, p.N, p.bias, p.act, p.colscale, p.residual, p.ldr, p.C, p.c_dtype,
-                                  p.ldc, hn ? hn_w0 : nullptr, hn ? hn_w1 : nullptr, hn_c0, hn_c1, 1e-6f, c.h->d.rms_mode, c.s), what);
+                                  p.ldc, hn ? hn_w0 : nullptr, hn ? hn_w1 : nullptr, hn_c0, hn_c1, 1e-6f, c.h->d.rms_mode, c.s, pfp, pfb), what);
 }
 
 // adaptor MLP: Linear (gelu_tanh Linear)*  — final layer writes `dst` (ld = D) with optional per-row-in-sample residual (pos embed)
