@@ -30,7 +30,10 @@ import json
 out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes), bench.py --steps 1 --warmup 1 --no-graph; bytes = 2*FETCH_SIZE + WRITE_SIZE (gfx950 correction)"}
 # class "gemm_pp256" = the 256-square ping-pong tile in both forms (vt_prof class 2): gemm_pp256d_kernel and the persistent gemm_pt_kernel
 for cls in ("gemm_pp256", "gemm_ppk", "gemm_pw_", "gemm_pws", "gemm_glds", "attn_kvt", "gemm_pt_kernel<unsigned short, 0"):
-    g = [r for r in rows if cls in r[1] or (cls == "gemm_pp256" and "gemm_pt_kernel" in r[1])]
+    if cls.startswith("gemm_pt_kernel"):      # the fused K|V projection in either 16-bit type: gemm_pt_kernel<unsigned short | half_t, 0, 0>
+        g = [r for r in rows if r[1].startswith("gemm_pt_kernel<") and r[1].rstrip().endswith(", 0, 0>")]
+    else:
+        g = [r for r in rows if cls in r[1] or (cls == "gemm_pp256" and "gemm_pt_kernel" in r[1])]
     tot = sum(r[0] for r in g); n = sum(r[2] for r in g)
     print(f"CLASS {cls}: dispatches={n} bytes={tot:.0f} per_launch_bytes={tot/max(n,1):.0f}")
     out["gemm_pt_kv" if cls.startswith("gemm_pt_kernel") else cls.rstrip("_")] = {"dispatches": n, "per_launch_bytes": tot / max(n, 1)}
