@@ -286,13 +286,15 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
         c.rs_pending = true;
       }
     }
-    static const bool pf_on = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return !e || atoi(e) != 0; }();
+    // prefetch hint for the next launch's weights: measured SLOWER (round 5, EXPERIMENTS.md: one batch at a time 363 -> 359 chunks/s, batch 1 20.31 -> 20.59 ms)
+    // — off unless VLATOUCH_RDT_PREFETCH=1
+    static const bool pf_on = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return e && atoi(e) != 0; }();
     if (pf_on && c.pf_next && p.Wp && vt_gemm_fast_eligible(p) && vt_gemm_pw_eligible(p)) { p.pf_ptr = c.pf_next; p.pf_bytes = c.pf_bytes; }
     c.pf_next = nullptr;
     return vt_wrap(vt_gemm_launch(p, c.s), what);
   }
   // split path (small batch): the slab reduction behind the GEMM carries the hint, on extra blocks of its own launch
-  static const bool pf_small = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return !e || atoi(e) != 0; }();
+  static const bool pf_small = [] { const char* e = getenv("VLATOUCH_RDT_PREFETCH"); return e && atoi(e) != 0; }();
   const void* pfp = pf_small ? c.pf_next : nullptr;
   const size_t pfb = c.pf_bytes;
   c.pf_next = nullptr;
