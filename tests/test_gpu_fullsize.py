@@ -56,11 +56,13 @@ def test_rdt_1b_batch_invariance_determinism_and_mask(rdt1b):
     scale = float(full.abs().max())
     # every sample alone (different first/last-tile alignment of its keys in the tile stream: 4374 % 64 != 0) == in the batch.
     # Not bit-exact: the K/V projection tiles see different row neighbours only through fp32 accumulation order -> none; the
-    # per-step GEMMs pick tile sizes from M, which changes the summation grouping of bf16 products.
+    # per-step GEMMs pick tile sizes from M, which changes the summation grouping of the 16-bit products.  Bar: the north-star tolerance on the
+    # result (1e-2 of its scale; round 4 allowed twice that with bf16 activations), compared in the returned dtype (bf16: half an ulp at the scale is 2e-3 .. 4e-3)
     for b in range(3):
         alone = run(rdt1b, d, slice(b, b + 1))
         e = float((alone[0] - full[b]).abs().max())
-        assert e <= 2e-2 * scale, (b, e, scale)
+        print(f"[RDT-1B batch invariance row {b}] {e:.3e} (scale {scale:.2f})")
+        assert e <= 1e-2 * scale, (b, e, scale)
     # language tokens under a False mask do not matter
     d2 = dict(d)
     d2["mask"] = d["mask"].clone()
@@ -255,7 +257,7 @@ def test_rdt_1b_50_steps_batch16(rdt1b):
         alone = run(rdt1b, d, slice(5, 6))
         e_inv = float((alone[0] - full[5]).abs().max())
         print(f"[RDT-1B 50 steps] scale {scale:.3f}  batch-invariance row 5: {e_inv:.3e}")
-        assert e_inv <= 2e-2 * scale, (e_inv, scale)
+        assert e_inv <= 1e-2 * scale, (e_inv, scale)
         ref = _oracle_episode(rdt1b, d, 0, 50)
         e = float((full[0].cpu() - ref).abs().max())
         rs = float(ref.abs().max())
