@@ -33,7 +33,11 @@ typedef const __attribute__((address_space(1))) void glb_void;
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int BUF_BYTES = (BM + BN) * 128;      // one k-tile: A rows 0..255 then B rows 0..255, 128 B each
 
+#ifdef VLATOUCH_DRAIN_WAITS      // debug build (tools/drain_waits_check.sh): counted waits drain the queue
+#define VT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
 #define VT_WAIT_VM(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#endif
 
 template <typename T16, typename TC, int CMAP>
 __global__ __launch_bounds__(512, 2) void gemm_pp256_kernel(const VtGemmParams p, const int tiles_n, const int tiles_per_group, const int total_tiles, const int GM) {

@@ -115,7 +115,11 @@ __device__ __forceinline__ float sum_rows4(float v) {
   return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
 }
 
+#ifdef VLATOUCH_DRAIN_WAITS      // debug build (tools/drain_waits_check.sh): every counted wait drains the whole queue — results must not change by a bit
+template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#else
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
 
 // ops allowed to stay in flight after phase `ph` of a k-tile of kind MODE has staged its unit (see the header).  NST = 4 stores per store slot.
 //   STEADY                       8 pieces

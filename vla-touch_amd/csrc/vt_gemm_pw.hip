@@ -65,7 +65,11 @@ __device__ __forceinline__ void pw_wload(int4_t& d, const unsigned voff, const c
 // counted wait that retires weight buffer w[0..3] (and everything older in this wave's queue, i.e. its DMA pieces of that k-tile)
 template <int N>
 __device__ __forceinline__ void pw_wait(int4_t (&w)[4]) {
+#ifdef VLATOUCH_DRAIN_WAITS      // debug build (tools/drain_waits_check.sh)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]) : [n] "i"(N) : "memory");
+#endif
 }
 
 template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) {

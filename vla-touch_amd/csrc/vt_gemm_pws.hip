@@ -55,7 +55,11 @@ __device__ __forceinline__ void pws_wload(int4_t& d, const unsigned voff, const 
 }
 template <int N>
 __device__ __forceinline__ void pws_wait(int4_t (&w)[8]) {
+#ifdef VLATOUCH_DRAIN_WAITS      // debug build (tools/drain_waits_check.sh)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : : "memory");
+#else
   asm volatile("s_waitcnt vmcnt(%[n])" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : [n] "i"(N) : "memory");
+#endif
 }
 
 template <typename T16, typename TC>

@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvlatouch_hip.so")
+# VLATOUCH_LIB: another build of the same library (tools/drain_waits_check.sh compares the product against a debug build); default = the in-tree product
+LIB_PATH = os.environ.get("VLATOUCH_LIB") or os.path.join(_HERE, "libvlatouch_hip.so")
 
 F32, BF16, F32X3, F16 = 0, 1, 2, 3   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only); F16: IEEE half
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH, ACT_SWIGLU = 0, 1, 2, 3, 4, 5
