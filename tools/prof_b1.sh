@@ -4,7 +4,7 @@ R=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 O=gpurun_out
-A="--batch 1 --streams 1 --no-cpu-baseline --warmup 2"
+A="--batch 1 --streams 1 --no-cpu-baseline --alt-compute-steps 0 --warmup 2"
 rocprofv3 --kernel-trace --stats -d $O/prof_b1a -o a -- python bench.py $A --steps 10 > /dev/null 2> $O/${R}_prof_b1.err
 rocprofv3 --kernel-trace --stats -d $O/prof_b1b -o b -- python bench.py $A --steps 50 > $O/${R}_prof_b1.json 2>> $O/${R}_prof_b1.err
 python tools/prof_per_step.py $(find $O/prof_b1a -name "*.db" | head -1) 10 $(find $O/prof_b1b -name "*.db" | head -1) 50 > $O/${R}_per_step_b1.txt

@@ -8,20 +8,20 @@ cd $GRAFT_REPO_ROOT
 O=gpurun_out
 mkdir -p $O/pmc
 # 1. per-kernel time of the headline command line (2 batches in flight, hipGraph)
-rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/${R}_prof_bench.json 2> $O/${R}_prof_bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof_full -o full -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --alt-compute-steps 0 > $O/${R}_prof_bench.json 2> $O/${R}_prof_bench.err
 python tools/prof_summary.py $(find $O/prof_full -name "*.db" | head -1) 10 > $O/${R}_full_kernel_stats.txt
 rm -rf $O/prof_full
 # 2. the same with one batch in flight (kernel durations without co-running kernels)
-rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o s1 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --streams 1 > $O/${R}_prof_bench_s1.json 2>> $O/${R}_prof_bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof_s1 -o s1 -- python bench.py --steps 5 --warmup 2 --no-cpu-baseline --alt-compute-steps 0 --streams 1 > $O/${R}_prof_bench_s1.json 2>> $O/${R}_prof_bench.err
 python tools/prof_summary.py $(find $O/prof_s1 -name "*.db" | head -1) 10 > $O/${R}_full_kernel_stats_streams1.txt
 cp $(find $O/prof_s1 -name "*.db" | head -1) $O/_s1_5.db
 rm -rf $O/prof_s1
 # 2b. the same with 13 steps: the difference of the two runs per step is free of set-up work (weight generation, packing, one-off copies)
-rocprofv3 --kernel-trace --stats -d $O/prof_s1b -o s1b -- python bench.py --steps 13 --warmup 2 --no-cpu-baseline --streams 1 > /dev/null 2>> $O/${R}_prof_bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof_s1b -o s1b -- python bench.py --steps 13 --warmup 2 --no-cpu-baseline --alt-compute-steps 0 --streams 1 > /dev/null 2>> $O/${R}_prof_bench.err
 python tools/prof_per_step.py $O/_s1_5.db 5 $(find $O/prof_s1b -name "*.db" | head -1) 13 > $O/${R}_per_step_streams1.txt
 rm -rf $O/prof_s1b $O/_s1_5.db
 # 3. PMC: HBM-side bytes (two passes), MFMA utilisation, SQ stalls — eager, one step
-PB="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-graph --streams 1"
+PB="python bench.py --steps 1 --warmup 1 --no-cpu-baseline --alt-compute-steps 0 --no-graph --streams 1"
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc -o pmc_$C -- $PB > /dev/null 2>> $O/${R}_prof_bench.err
 done
