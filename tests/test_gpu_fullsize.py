@@ -218,31 +218,35 @@ def test_rdt_1b_batch32_rows_vs_oracle(rdt1b):
         assert e <= 1e-2 * max(1.0, scale), (b, e, scale)
 
 
-def test_rdt_1b_batch32_bf16_activations_vs_oracle():
-    """The same B = 32 configuration with the reference's own execution dtype for the activations (compute_dtype="bf16"; the default is IEEE fp16):
-    still within 1e-2 of the output scale, and the fp16 default is at least 3x closer on the same inputs."""
+def test_rdt_1b_batch32_activation_types_and_rmsnorm_forms_vs_oracle():
+    """The same B = 32 configuration (M = 2144 rows: weights-in-registers tiles with the RMSNorm hand-off, persistent K|V projection, cached
+    cross-attention) in the OTHER settings a deployment can ask for, row 0 against the oracle: the reference's own execution dtype for the activations
+    (compute_dtype="bf16": within 1e-2 of the output scale; the fp16 default at least 3x closer on the same inputs), and timm <= 1.0.8's variance
+    RmsNorm (what released RDT-1B checkpoints need: hand-off with row sums, online softmax) with fp16 activations."""
     from models.rdt_runner import RDTRunner
     from vlatouch import synth
-    cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": "meansq"}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
-           "state_adaptor": "mlp3x_gelu",
-           "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": 5, "beta_schedule": "squaredcos_cap_v2",
-                               "prediction_type": "sample", "clip_sample": False}}
     d = rdt_inputs(32, seed=17)
-    errs = {}
-    ref = None
-    for compute in ("bf16", "f16"):
+    errs, scales = {}, {}
+    refs = {}
+    for compute, rms in (("bf16", "meansq"), ("f16", "meansq"), ("f16", "var")):
+        cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": rms}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
+               "state_adaptor": "mlp3x_gelu",
+               "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": 5, "beta_schedule": "squaredcos_cap_v2",
+                                   "prediction_type": "sample", "clip_sample": False}}
         r = RDTRunner(action_dim=128, pred_horizon=64, config=cfg, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128, max_lang_cond_len=1024,
                       img_cond_len=4374, dtype=torch.bfloat16, device=DEV, init_weights=False, compute_dtype=compute)
         r.load_state_dict(synth.fill_state_dict_device(synth.rdt_runner_shapes(**RDT1B), torch.device(DEV), torch.bfloat16, seed=7), assign=True)
         out = r.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=d["x0"], return_fp32=True)
-        if ref is None:
-            ref = _oracle_episode(r, d, 0, 5)
-        errs[compute] = float((out[0].cpu() - ref).abs().max())
+        if rms not in refs:
+            refs[rms] = _oracle_episode(r, d, 0, 5)
+        errs[(compute, rms)] = float((out[0].cpu() - refs[rms]).abs().max())
+        scales[rms] = float(refs[rms].abs().max())
         del r, out
         torch.cuda.empty_cache()
-    scale = float(ref.abs().max())
-    print(f"[RDT-1B B=32 row 0] scale {scale:.3f}  |hip - oracle32|: bf16 activations {errs['bf16']:.3e}, fp16 activations {errs['f16']:.3e}")
-    assert errs["bf16"] <= 1e-2 * max(1.0, scale) and errs["f16"] <= 2.5e-3 * max(1.0, scale) and 3 * errs["f16"] <= errs["bf16"], errs
+    print("[RDT-1B B=32 row 0] |hip - oracle32|: " + ", ".join(f"{c} activations / {m}: {e:.3e} (scale {scales[m]:.2f})" for (c, m), e in errs.items()))
+    s_ms, s_var = max(1.0, scales["meansq"]), max(1.0, scales["var"])
+    assert errs[("bf16", "meansq")] <= 1e-2 * s_ms and errs[("f16", "meansq")] <= 2.5e-3 * s_ms and 3 * errs[("f16", "meansq")] <= errs[("bf16", "meansq")], errs
+    assert errs[("f16", "var")] <= 2.5e-3 * s_var, errs
 
 
 def test_rdt_1b_50_steps_batch16(rdt1b):
