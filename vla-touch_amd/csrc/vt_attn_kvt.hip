@@ -260,14 +260,14 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   float4_t o[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;
   const float cscale = p.scale * 1.4426950408889634f;
   // FIXED: the bound is already in scaled-score units.  IEEE fp16 probabilities have 5 exponent bits: exp(s - B) in (e^-2B, 1] would sit in (and below)
   // the subnormals for every row whose largest score is well under the bound, so the fp16 form shifts the exponent up by 15 octaves (P in (2^15 e^-2B, 2^15],
   // the largest finite fp16 is 65504): the row sum l carries the same factor and O / l cancels it; the launcher admits bounds up to 16 only (40 for bf16)
   constexpr float P_SHIFT = std::is_same<T, half_t>::value ? 15.0f : 0.0f;
   const float fixed_mc = p.fixed_max * 1.4426950408889634f - P_SHIFT;
-  float4_t lacc = {0.f, 0.f, 0.f, 0.f};                           // FIXED: row sums of P on the matrix pipe (every row of the tile = l)
+  float4_t lacc = {0.f, 0.f, 0.f, 0.f};                           // row sums of P on the matrix pipe (every row of the tile = l)
   Frag<T> ones;
   constexpr short one16 = KvtOne<T>::v;
   ones.v = (short8_t){one16, one16, one16, one16, one16, one16, one16, one16};
@@ -336,7 +336,9 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
       const float m_new = fmaxf(m_run, mx);
       if (__any(m_new != m_run)) {
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
-        l_run *= alpha;
+        // the row sums live on the matrix pipe here too (round 5; below): lacc's four rows all hold l of query l15, so they take the lane's own alpha
+#pragma unroll
+        for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -344,10 +346,8 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
         m_run = m_new;
       }
       const float mc = (m_run == -INFINITY) ? 0.f : m_run * cscale;
-      float psum = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc)); psum += sv[i]; }
-      l_run += psum;
+      for (int i = 0; i < 16; ++i) sv[i] = __builtin_amdgcn_exp2f(fmaf(sv[i], cscale, -mc));
     }
     Frag<T> pf[2];
 #pragma unroll
@@ -379,22 +379,15 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
         }
         mma16(o[dt], vf, pf[kb]);
       }
-    if constexpr (FIXED) {
-      // masked (partial-tile) keys already have P = 0 (their scores were -inf), so the ones fragment needs no masking
-      mma16(lacc, ones, pf[0]);
-      mma16(lacc, ones, pf[1]);
-    }
+    // row sums of P on the matrix pipe, in BOTH softmax forms (round 5: the online form summed them on the VALU + two cross-lane steps): one MFMA per 32 keys
+    // against a fragment of ones sums exactly the 16-bit P that multiplies V and arrives reduced over the lanes.  Masked (partial-tile) keys already have
+    // P = 0 (their scores were -inf), so the ones fragment needs no masking.
+    mma16(lacc, ones, pf[0]);
+    mma16(lacc, ones, pf[1]);
     slot = next_slot(slot);
   }
-  float l;
-  if constexpr (FIXED) {
-    l = lacc[0];
-    m_run = p.fixed_max / p.scale;                   // the parts path stores m in raw-score units
-  } else {
-    l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-  }
+  const float l = lacc[0];
+  if constexpr (FIXED) m_run = p.fixed_max / p.scale;                   // the parts path stores m in raw-score units
   if (p.parts > 1) {
     float* W = p.part_ws + ((((long)b * p.H + h) * p.parts + part) * (nw * 16) + wave * 16 + l15) * 66;
 #pragma unroll
