@@ -26,6 +26,21 @@ template <> __device__ __forceinline__ uint32_t kvt_pk<bf16_t>(float lo, float h
 template <> __device__ __forceinline__ uint32_t kvt_pk<half_t>(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, __builtin_convertvector((float2_t){lo, hi}, kvt_half2_t));
 }
+// max over the four 16-lane rows of a wave (lanes that differ in bits 4 and 5), result in every lane, on v_permlane16_swap / v_permlane32_swap
+// (two VALU ops) instead of two __shfl_xor = ds_bpermute round trips through the LDS crossbar
+__device__ __forceinline__ float kvt_max_rows4(float v) {
+#ifdef VLATOUCH_KVT_MAX_SHFL
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+#else
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+  const unsigned x = __builtin_bit_cast(unsigned, w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+#endif
+}
 template <typename T> struct KvtOne;      // 1.0 in the 16-bit type (the fragment of ones that sums P on the matrix pipe)
 template <> struct KvtOne<bf16_t> { static constexpr short v = 0x3f80; };
 template <> struct KvtOne<half_t> { static constexpr short v = 0x3c00; };
@@ -331,8 +346,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
       float mx = sv[0];
 #pragma unroll
       for (int i = 1; i < 16; ++i) mx = fmaxf(mx, sv[i]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = kvt_max_rows4(mx);
       const float m_new = fmaxf(m_run, mx);
       if (__any(m_new != m_run)) {
         const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_new) * cscale);
