@@ -14,6 +14,7 @@ run full_streams1_n1 --streams 1 --no-cpu-baseline
 run full_streams4_n1 --streams 4 --no-cpu-baseline
 run full_rmsvar_n1 --rms-mode var --no-cpu-baseline
 run full_bf16act_n1 --rdt-compute bf16 --no-cpu-baseline
+VLATOUCH_ATTN_FIXEDMAX=0 run full_online_softmax_n1 --no-cpu-baseline
 run full_tactile64_n1 --force-dim 64 --no-cpu-baseline
 run pi_refine_n1 --workload pi_refine --no-cpu-baseline
 run pi_refine_streams1_n1 --workload pi_refine --no-cpu-baseline --streams 1
