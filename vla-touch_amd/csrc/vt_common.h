@@ -123,7 +123,25 @@ __device__ __forceinline__ float act_apply(float x, int act) {
   }
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
+// sum / max over the 64 lanes, result in every lane.  Round 5: inside a row of 16 on DPP lane permutes, across the four rows on v_permlane16_swap /
+// v_permlane32_swap — all VALU — instead of six __shfl_xor = ds_bpermute round trips through the LDS crossbar (-DVLATOUCH_WAVE_SHFL keeps the butterfly for A/B).
+__device__ __forceinline__ float rows4_sum(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+  const unsigned x = __builtin_bit_cast(unsigned, w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+}
+__device__ __forceinline__ float rows4_max(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  const float w = fmaxf(__builtin_bit_cast(float, (unsigned)a[0]), __builtin_bit_cast(float, (unsigned)a[1]));
+  const unsigned x = __builtin_bit_cast(unsigned, w);
+  const auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+  return fmaxf(__builtin_bit_cast(float, (unsigned)b[0]), __builtin_bit_cast(float, (unsigned)b[1]));
+}
+__device__ __forceinline__ float wave_sum_shfl(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
@@ -141,11 +159,27 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += dpp(v, std::integral_constant<int, 0x140>{});   // row_mirror
   return v;
 }
+__device__ __forceinline__ float row16_max(float v) {
+  auto dpp = [](float x, auto ctrl) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+  };
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0xB1>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x4E>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x141>{}));
+  v = fmaxf(v, dpp(v, std::integral_constant<int, 0x140>{}));
+  return v;
+}
+#ifdef VLATOUCH_WAVE_SHFL
+__device__ __forceinline__ float wave_sum(float v) { return wave_sum_shfl(v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+#else
+__device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }
+__device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
+#endif
 
 // generic typed load/store as float
 template <typename T> __device__ __forceinline__ float ldf(const T* p, size_t i);
