@@ -32,7 +32,7 @@ __device__ __forceinline__ float4_t ldv(const float* p) { return *reinterpret_ca
 __device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
 
 // sum over each aligned group of `n` lanes (n = 1, 2, 4 ... 64, wave-uniform), result in every lane: DPP inside a row of 16 (no LDS
-// crossbar round trips), two ds_bpermute steps across rows
+// crossbar round trips), permlane swaps across rows
 __device__ __forceinline__ float seg_sum(float v, int n) {
   auto dpp = [](float x, auto ctrl) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
@@ -41,8 +41,17 @@ __device__ __forceinline__ float seg_sum(float v, int n) {
   if (n >= 4) v += dpp(v, std::integral_constant<int, 0x4E>{});    // quad_perm [2,3,0,1]
   if (n >= 8) v += dpp(v, std::integral_constant<int, 0x141>{});   // row_half_mirror
   if (n >= 16) v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
-  if (n >= 32) v += __shfl_xor(v, 16, 64);
-  if (n >= 64) v += __shfl_xor(v, 32, 64);
+  // across rows: v_permlane16_swap pairs rows (0,1) and (2,3), v_permlane32_swap the two halves — VALU, no ds_bpermute round trip (round 5)
+  if (n >= 32) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto a = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)a[0]) + __builtin_bit_cast(float, (unsigned)a[1]);
+  }
+  if (n >= 64) {
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto b = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __builtin_bit_cast(float, (unsigned)b[0]) + __builtin_bit_cast(float, (unsigned)b[1]);
+  }
   return v;
 }
 
@@ -490,9 +499,7 @@ __global__ __launch_bounds__(1024) void ufinal_kernel(const UFinalParams p) {
         for (int d = 0; d < 16; ++d) if (d < p.dim) s[d] += a * wl[d * C + c];
       }
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int d = 0; d < 16; ++d) s[d] += __shfl_xor(s[d], o, 64);
+      for (int d = 0; d < 16; ++d) s[d] = wave_sum(s[d]);            // DPP + permlane swaps (vt_common.h)
 #pragma unroll
       for (int d = 0; d < 16; ++d) if (lane == d && d < p.dim) outv[net][t * 16 + d] = s[d] + outb[net][d];
     }
