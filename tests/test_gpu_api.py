@@ -238,11 +238,11 @@ def test_predict_edge_shapes_vs_oracle(controllers, B, T, res, layout):
     assert err(got, ref.numpy()) < TOL["fp32"], err(got, ref.numpy())
 
 
-@pytest.mark.parametrize("B,size,force_dim", [(2, "small", 64), (32, "base", 64), (3, "small", 1), (4, "small", 17)])
+@pytest.mark.parametrize("B,size,force_dim", [(2, "small", 64), (32, "base", 64), (4, "small", 17)])
 def test_predict_tactile_vector_widths_vs_oracle(B, size, force_dim):
     """The tactile input m_t at other widths than the marker tracker's 3-d force estimate: `force_dim` is a constructor argument of the
     reference (bridge_controller.py:25; obs_dim = 2*latent + state_dim + force_dim, :40-48; cat at :129-132) and BASELINE.json's synthetic
-    workload names a 64-d tactile vector.  B = 32 / DINOv2-base / 64-d is that workload's pi_I leg exactly; 1 and 17 make the concatenated
+    workload names a 64-d tactile vector.  B = 32 / DINOv2-base / 64-d is that workload's pi_I leg exactly; 17 makes the concatenated
     row end off every padding boundary of the observation MLP's first Linear.  Both precisions against the oracle run live."""
     from oracle import controller as oc
     from residual_controller.bridge_controller import DiffusionController

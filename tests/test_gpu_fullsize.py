@@ -192,8 +192,19 @@ def test_bench_pattern_full_graphs_in_flight_are_bit_identical_to_one(rdt1b):
 
 
 # ---------------------------------------------------------------- full-size parity against the oracle
+_ORACLE_CACHE = {}
+
+
 def _oracle_episode(r, d, b, steps):
-    """The oracle's predict_action (fp32 math) on episode b alone, with the runner's bf16-rounded weights, inputs and start noise."""
+    """The oracle's predict_action (fp32 math) on episode b alone, with the runner's bf16-rounded weights, inputs and start noise.  Every runner of this file
+    carries the same seed-7 weights, so a result is reused for the same inputs (keyed by a checksum of the episode's inputs): the oracle costs ~10 s per episode."""
+    key = (b, steps, r.rms_mode, float(d["x0"][b].double().sum()), float(d["img"][b].double().sum()), float(d["lang"][b].double().sum()))
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = _oracle_episode_uncached(r, d, b, steps)
+    return _ORACLE_CACHE[key]
+
+
+def _oracle_episode_uncached(r, d, b, steps):
     from oracle import rdt as orr
     torch.set_num_threads(max(1, min(32, len(__import__("os").sched_getaffinity(0)))))
     sd = {k: v.float().cpu() for k, v in r.state_dict().items()}
