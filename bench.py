@@ -23,6 +23,11 @@ import os
 import sys
 import time
 
+# the CPU-baseline leg sweeps torch's intra-op thread count: OpenMP workers must SLEEP between parallel regions (the default spin-wait makes large teams
+# stall each other); read by the OpenMP runtime when torch loads it, so set before `import torch`.  No effect on the GPU path.
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "vla-touch_amd")):
     if p not in sys.path:
@@ -52,9 +57,10 @@ def parse():
     ap.add_argument("--rms-mode", default="meansq", choices=["meansq", "var"],
                     help="timm RmsNorm arithmetic of RDT: meansq = timm >= 1.0.9; var = timm <= 1.0.8 incl. the timm==1.0.3 upstream RDT-1B pins (what its "
                          "released checkpoints need): no score bound exists there, so the cached cross-attention runs its ONLINE softmax")
-    ap.add_argument("--rdt-compute", default="f16", choices=["f16", "bf16"],
-                    help="16-bit activation / MFMA operand type of the bf16 RDT-1B: f16 = IEEE fp16 (default: the bf16 weights convert exactly, same width and "
-                         "MFMA rate, |chunk - fp32 oracle| 8x smaller), bf16 = the reference's own execution dtype")
+    ap.add_argument("--rdt-compute", default="auto", choices=["auto", "f16", "bf16"],
+                    help="16-bit activation / MFMA operand type of the bf16 RDT-1B: auto (the product default) = IEEE fp16 under the engine's range guard, falling "
+                         "back to bf16 when a value leaves the fp16 range (the record's `range_guard` says what happened); f16 / bf16 pin the type (f16: the bf16 "
+                         "weights convert exactly, same width and MFMA rate, |chunk - fp32 oracle| 8x smaller; bf16 = the reference's own execution dtype)")
     ap.add_argument("--lang-len", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a captured hipGraph")
     ap.add_argument("--streams", type=int, default=0,
@@ -66,7 +72,8 @@ def parse():
     ap.add_argument("--overlap", dest="no_overlap", action="store_false", default=True,
                     help="run the observation encoding on a second HIP stream beside the RDT chunk generation (measured: <1 %% gain)")
     ap.add_argument("--cpu-iters", type=int, default=2)
-    ap.add_argument("--cpu-threads", type=int, default=32)
+    ap.add_argument("--cpu-threads", default="32,64,128", help="thread counts of the CPU-baseline sweep (comma separated, each capped by the affinity mask)")
+    ap.add_argument("--no-var-chain", action="store_true", help="skip the cpu_baseline leg's chained-parity check with timm==1.0.3's variance RmsNorm (one more oracle episode, ~10 s)")
     ap.add_argument("--cpu-batch", type=int, default=8, help="episodes in the CPU-baseline sample of the pi_I leg")
     ap.add_argument("--force-dim", type=int, default=3,
                     help="width of the tactile vector m_t fed to the observation MLP (reference default 3 = the marker tracker's force estimate, "
@@ -383,11 +390,18 @@ def main():
 
     # ---- the same timed pattern with the other 16-bit activation type of RDT-1B (f16 <-> bf16): a second runner on the SAME weights, its own
     #      workspaces and graphs; reported beside the headline so that the record carries what the choice of the default costs / buys
+    # the 16-bit type RDT-1B actually ran in ("auto" starts in fp16 and falls back to bf16 only if the range guard fires) + the guards' sticky words, read once here
+    rdt_used = "f16" if (rdt is not None and rdt.compute_dtype == torch.float16) else "bf16"
+    range_guard = None
+    if rdt is not None and args.precision == "bf16":
+        bits = rdt.overflowed()
+        range_guard = {"rdt_compute_requested": args.rdt_compute, "rdt_compute_used": rdt_used, "rdt_flag": bits, "rdt_flag_names": L.range_names(bits),
+                       "note": "sticky device word OR-ed by the kernels of every step of this run (warm-up, graph replays, timed region): 0 = no value left the compute type's range"}
     alt_elapsed = None
     if rdt is not None and args.precision == "bf16" and args.alt_compute_steps > 0 and args.workload in ("full", "rdt"):
         try:                                            # a side measurement: it must never take the headline line down with it
             from models.rdt_runner import RDTRunner as _RR
-            alt_mode = "bf16" if args.rdt_compute == "f16" else "f16"
+            alt_mode = "bf16" if rdt_used == "f16" else "f16"
             rdt_alt = _RR(action_dim=128, pred_horizon=64, config=cfg, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128, max_lang_cond_len=1024,
                           img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False, compute_dtype=alt_mode)
             rdt_alt.load_state_dict(rdt.state_dict(), assign=True)
@@ -470,9 +484,9 @@ def main():
         "value": round(value, 2), "unit": "frames/s" if args.workload == "marker" else "chunks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000 * elapsed / args.steps, 4), "p50_step_latency_ms": round(p50, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": ("bf16 model, 16-bit activations in IEEE fp16 (RDT-1B --rdt-compute f16, DINOv2 tower; same width and MFMA rate as bf16)" if args.rdt_compute == "f16"
+        "dtype": ("bf16 model, 16-bit activations in IEEE fp16 (RDT-1B --rdt-compute f16, DINOv2 tower; same width and MFMA rate as bf16)" if rdt_used == "f16"
                   else "bf16 (DINOv2 tower: IEEE fp16)") if args.precision == "bf16" else "fp32",
-        "dtypes": ({"rdt": ("bf16 weights converted exactly to IEEE fp16, fp16 activations + f16 MFMA" if args.rdt_compute == "f16" else "bf16 storage + bf16 MFMA")
+        "dtypes": ({"rdt": ("bf16 weights converted exactly to IEEE fp16, fp16 activations + f16 MFMA" if rdt_used == "f16" else "bf16 storage + bf16 MFMA")
                            + ", fp32 residual stream, accumulation and solver state", "dinov2": "IEEE fp16 storage + f16 MFMA, fp32 residual stream",
                     "siglip": "IEEE fp16 storage + f16 MFMA", "obs_mlp": "fp32", "unet_sampler": "fp32 storage, split-bf16 (3 bf16 MFMAs per product)",
                     "lstm_head": "fp32 storage, split-bf16"} if args.precision == "bf16" else {"all": "fp32 storage + fp32 MFMA"}),
@@ -483,7 +497,7 @@ def main():
             "hipgraph": graph is not None, "batches_in_flight": n_streams, "inputs": "one synthetic input set per batch in flight (no sharing between slots)",
             "tactile_vector_dim": args.force_dim,
             "ms_per_step_semantics": "wall time of the timed region / steps; with batches_in_flight > 1 consecutive steps (independent batches) "
-                                     "overlap on separate HIP streams, so p50_step_latency_ms (enqueue -> completion of one batch) exceeds ms_per_step", "rdt_mode": (("IEEE fp16" if args.rdt_compute == "f16" else "bf16") + " storage + MFMA (bf16 model), fp32 residual stream") if args.precision == "bf16" else "fp32",
+                                     "overlap on separate HIP streams, so p50_step_latency_ms (enqueue -> completion of one batch) exceeds ms_per_step", "rdt_mode": (("IEEE fp16" if rdt_used == "f16" else "bf16") + " storage + MFMA (bf16 model), fp32 residual stream") if args.precision == "bf16" else "fp32",
             "dino_mode": "IEEE fp16 storage + f16 MFMA, fp32 residual stream" if args.precision == "bf16" else "fp32", "unet_mode": "split-bf16 (3 bf16 MFMAs/k-step, fp32 storage)" if args.precision == "bf16" else "fp32 MFMA",
             "weights": "random-init synthetic of the named architectures (no checkpoints offline; RDT-1B hyper-parameters are upstream's, "
                        "not in the reference)", "setup_s": round(setup_s, 1),
@@ -497,8 +511,10 @@ def main():
     elif n_streams == 1:
         res["latency_mode"] = {"chunks_per_s": res["value"], "ms_per_step": res["ms_per_step"], "steps": args.steps, "batches_in_flight": 1,
                                "note": "the timed region itself (one batch in flight)"}
+    if range_guard is not None:
+        res["range_guard"] = range_guard
     if alt_elapsed is not None:
-        res["alt_rdt_compute"] = {"rdt_compute": "bf16" if args.rdt_compute == "f16" else "f16", "chunks_per_s": round(B * world * args.alt_compute_steps / alt_elapsed, 2),
+        res["alt_rdt_compute"] = {"rdt_compute": "bf16" if rdt_used == "f16" else "f16", "chunks_per_s": round(B * world * args.alt_compute_steps / alt_elapsed, 2),
                                   "ms_per_step": round(1000 * alt_elapsed / args.alt_compute_steps, 4), "steps": args.alt_compute_steps, "batches_in_flight": n_streams,
                                   "note": "the same step with the other 16-bit activation type of RDT-1B (bf16 = the reference's execution dtype: |chunk - fp32 oracle| "
                                           "~8e-3..1.1e-2; f16 = the default: ~1e-3), same weights, same box, timed right after the headline"}
@@ -611,12 +627,14 @@ def main():
         res["roofline_other"] = [r for r in (r_at, r_uc) if r is not None]
 
     # ---- CPU baseline: the oracle (fp32 torch ops on the host cores), rank 0, N=1 only, on a BOUNDED sample:
-    #      pi_I leg on CB episodes; RDT leg on ONE episode (the reference's own schedule: K/V re-projected every step).
-    #      chunks/s = 1 / (t_pi / CB + t_rdt).  Threads are capped: oversubscribed OpenMP teams stall in spin barriers.
+    #      pi_I leg on CB episodes; RDT leg on whole episodes (the reference's own schedule: K/V re-projected every step).
+    #      chunks/s = 1 / (t_pi / CB + t_rdt).  Round 6: the thread count is SWEPT (--cpu-threads 32,64,128, passive OpenMP waits — set at the top of this
+    #      file, before torch loads its OpenMP runtime) on the pi_I leg and on a one-denoise-step probe of the RDT leg; the timed legs run at the best count of
+    #      each, `cores` = the count of the dominant (RDT) leg, the rest of the sweep is in `cores_sweep`.
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload in ("pi_refine", "full"):
         from oracle import controller as oc
-        cores = max(1, min(len(os.sched_getaffinity(0)), args.cpu_threads))
-        torch.set_num_threads(cores)
+        avail = len(os.sched_getaffinity(0))
+        cand = sorted({max(1, min(avail, int(c))) for c in str(args.cpu_threads).split(",") if c.strip()})
         CB = min(B, args.cpu_batch)
         cpu = {k: v[:CB].cpu() for k, v in inp.items()}
         z = torch.randn(10, CB, T, 10)
@@ -624,43 +642,86 @@ def main():
                synth.torch_state_dict(synth.si_net_shapes(10, 256), prefix="si.", salt="ema"), synth.unit_stats())
         heads = 12 if args.dino == "base" else 6
         f = lambda: oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"], cpu["vla"], cpu["cam1"], cpu["cam2"], cpu["forces"], z)
-        t1 = time.perf_counter(); ref = f(); first = time.perf_counter() - t1     # also the parity check of the benchmarked config
-        ts = [first]
-        if first < 15.0:
-            for _ in range(args.cpu_iters):
+        torch.set_num_threads(cand[0])
+        ref = f()                                                          # untimed first call (one-time costs); also the parity check of the benchmarked config
+        sweep = {}
+        for c in cand:
+            torch.set_num_threads(c)
+            ts = []
+            for _ in range(max(1, args.cpu_iters)):
                 t1 = time.perf_counter(); f(); ts.append(time.perf_counter() - t1)
-            ts = ts[1:]
-        t_pi = float(np.median(ts)) / CB
+            sweep[c] = {"pi_s_per_chunk": round(float(np.median(ts)) / CB, 4)}
+        c_pi = min(cand, key=lambda c: sweep[c]["pi_s_per_chunk"])
+        t_pi = sweep[c_pi]["pi_s_per_chunk"]
+        cores = c_pi
         got = ctrl.predict(inp["state"][:CB], inp["vla"][:CB], inp["cam1"][:CB], inp["cam2"][:CB], inp["forces"][:CB], noise=z.to(dev)).cpu()
-        sample = f"pi_I: {len(ts)} oracle predict() call(s) on {CB} episodes"
+        sample = f"pi_I: {max(1, args.cpu_iters)} oracle predict() call(s) on {CB} episodes at {c_pi} threads"
         t_rdt = 0.0
+        parity = {}
         if args.workload == "full":
             from oracle import rdt as orr
             sd_cpu = {k: v.float().cpu() for k, v in rdt.state_dict().items()}
-            c1 = {k: (v[:1].float().cpu() if v.dtype != torch.bool else v[:1].cpu()) for k, v in rin.items()}
-            # the SAME start noise for the GPU batch and the oracle's episode 0: the timed oracle run doubles as the parity check of
+            ep = lambda b: {k: (v[b:b + 1].float().cpu() if v.dtype != torch.bool else v[b:b + 1].cpu()) for k, v in rin.items()}
+            # the SAME start noise for the GPU batch and the oracle's episodes: the timed oracle run doubles as the parity check of
             # the benchmarked configuration (B = 32 rows through the large-batch kernels; oracle = fp32 math on the bf16-rounded weights)
             gx = torch.Generator(device=dev).manual_seed(99)
             x_init = torch.randn(B, 64, 128, generator=gx, device=dev, dtype=torch.float32).to(rdt_dtype)
             zc = torch.randn(10, B, T, 10)
-            with torch.cuda.stream(stream):
-                # the chunk as the step hands it over (fp32 buffer of the solver), then the CHAIN of the step on the same inputs: first T ticks x 10 EEF
-                # dims -> predict (all B episodes)
-                chunk32 = rdt.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init, return_fp32=True)
-                gpu_chunk = chunk32
-                gpu_chain = ctrl.predict(inp["state"], _ops.slice_cast(chunk32, T, 10), inp["cam1"], inp["cam2"], inp["forces"], noise=zc.to(dev))
-                stream.synchronize()
-            t1 = time.perf_counter()
-            ref_chunk = orr.predict_action(sd_cpu, c1["lang"], c1["mask"], c1["img"], c1["state"], c1["amask"], c1["freq"], x_init[:1].float().cpu(),
-                                           heads=32, horizon=64, num_inference_steps=args.rdt_steps, rms_mode=rdt.rms_mode)
-            t_rdt = time.perf_counter() - t1
-            rdt_diff = float((gpu_chunk[0].float().cpu() - ref_chunk[0]).abs().max())
-            rdt_scale = float(ref_chunk.abs().max())
-            sample += f"; RDT-1B: 1 oracle predict_action on 1 episode ({args.rdt_steps} steps, fp32)"
-            # a_hat of episode 0 through the oracle's own chain: oracle chunk -> oracle predict (the quantity the 1e-2 tolerance is stated on)
-            ref_chain = oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu["state"][:1], ref_chunk[:1, :T, :10], cpu["cam1"][:1], cpu["cam2"][:1],
-                                   cpu["forces"][:1], zc[:, :1])
-            chain_diff = float((gpu_chain[0].cpu() - ref_chain[0]).abs().max())
+
+            def gpu_chain_of(runner):
+                with torch.cuda.stream(stream):
+                    # the chunk as the step hands it over (fp32 buffer of the solver), then the CHAIN of the step on the same inputs: first T ticks x 10 EEF dims -> predict
+                    ch = runner.predict_action(rin["lang"], rin["mask"], rin["img"], rin["state"], rin["amask"], rin["freq"], x_init=x_init, return_fp32=True)
+                    an = ctrl.predict(inp["state"], _ops.slice_cast(ch, T, 10), inp["cam1"], inp["cam2"], inp["forces"], noise=zc.to(dev))
+                    stream.synchronize()
+                return ch.float().cpu(), an.cpu()
+
+            def oracle_episode(b, rms, steps=args.rdt_steps):
+                c1 = ep(b)
+                t1 = time.perf_counter()
+                rc = orr.predict_action(sd_cpu, c1["lang"], c1["mask"], c1["img"], c1["state"], c1["amask"], c1["freq"], x_init[b:b + 1].float().cpu(),
+                                        heads=32, horizon=64, num_inference_steps=steps, rms_mode=rms)
+                return rc, time.perf_counter() - t1
+
+            def chain_diffs(b, rc, gpu_chunk, gpu_chain):
+                one = slice(b, b + 1)
+                cpu1 = {k: v[one].cpu() for k, v in inp.items()}
+                ref_chain = oc.predict(sds[0], heads, sds[1], sds[2], sds[3], cpu1["state"], rc[:1, :T, :10], cpu1["cam1"], cpu1["cam2"], cpu1["forces"], zc[:, one])
+                return float((gpu_chunk[b] - rc[0]).abs().max()), float((gpu_chain[b] - ref_chain[0]).abs().max()), float(rc.abs().max())
+
+            gpu_chunk, gpu_chain = gpu_chain_of(rdt)
+            # one-denoise-step probe of the RDT leg at every thread count (a fifth of an episode's work each), then whole episodes at the best count
+            for c in cand:
+                torch.set_num_threads(c)
+                sweep[c]["rdt_one_step_probe_s"] = round(oracle_episode(0, rdt.rms_mode, steps=1)[1], 3)
+            cores = min(cand, key=lambda c: sweep[c]["rdt_one_step_probe_s"])
+            torch.set_num_threads(cores)
+            rows = sorted({0, B - 1})
+            t_eps = []
+            for b in rows:
+                rc, dt_ = oracle_episode(b, rdt.rms_mode)
+                t_eps.append(dt_)
+                e_chunk, e_chain, sc = chain_diffs(b, rc, gpu_chunk, gpu_chain)
+                parity[f"row{b}"] = {"chunk": e_chunk, "a_hat_chain": e_chain, "chunk_scale": sc}
+            t_rdt = float(np.mean(t_eps))
+            rdt_diff, chain_diff, rdt_scale = parity["row0"]["chunk"], max(v["a_hat_chain"] for v in parity.values()), parity["row0"]["chunk_scale"]
+            sample += f"; RDT-1B: {len(rows)} oracle predict_action calls on 1 episode each (rows {rows}, {args.rdt_steps} steps, fp32) at {cores} threads"
+            # the chain in the arithmetic released RDT-1B checkpoints need (timm==1.0.3 variance RmsNorm, models/rdt/blocks.py:22): a second runner on the same weights, episode 0
+            if not args.no_var_chain and rdt.rms_mode != "var":
+                try:
+                    from models.rdt_runner import RDTRunner as _RV
+                    cfg_v = dict(cfg, rdt=dict(cfg["rdt"], rms_norm="var"))
+                    rdt_v = _RV(action_dim=128, pred_horizon=64, config=cfg_v, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128, max_lang_cond_len=1024,
+                                img_cond_len=4374, dtype=rdt_dtype, device=dev, init_weights=False, compute_dtype=args.rdt_compute)
+                    rdt_v.load_state_dict(rdt.state_dict(), assign=True)
+                    ch_v, an_v = gpu_chain_of(rdt_v)
+                    rc_v, _ = oracle_episode(0, "var")
+                    e_chunk, e_chain, sc = chain_diffs(0, rc_v, ch_v, an_v)
+                    parity["row0_var_rmsnorm"] = {"chunk": e_chunk, "a_hat_chain": e_chain, "chunk_scale": sc, "range_flag": rdt_v.overflowed()}
+                    del rdt_v, ch_v, an_v
+                    torch.cuda.empty_cache()
+                except Exception as e:          # pragma: no cover  (a side check: it must not take the line down)
+                    parity["row0_var_rmsnorm"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             cpu_model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
         except Exception:
@@ -678,18 +739,22 @@ def main():
             n_phys = None
         res["cpu_baseline"] = {"value": round(1.0 / (t_pi + t_rdt), 3), "unit": "chunks/s", "cores": cores, "cpu_model": cpu_model,
                                "host_logical_cpus": os.cpu_count(), "host_physical_cores": n_phys,
-                               "cores_note": f"{cores} torch intra-op threads of {n_phys} physical cores / {os.cpu_count()} logical CPUs (more threads stall in OpenMP spin barriers); "
+                               "cores_sweep": {str(c): v for c, v in sweep.items()},
+                               "cores_note": f"torch intra-op threads swept over {cand} (OMP_WAIT_POLICY={os.environ.get('OMP_WAIT_POLICY')}, KMP_BLOCKTIME={os.environ.get('KMP_BLOCKTIME')}) of "
+                                             f"{n_phys} physical cores / {os.cpu_count()} logical CPUs; each leg timed at its best count (pi_I {c_pi}, RDT {cores}); `cores` = the RDT leg's (97 % of the time); "
                                              "a bounded sample, not the same amount of work as a GPU step",
                                "kind": "port", "sample": sample,
                                "pi_s_per_chunk": round(t_pi, 4), "rdt_s_per_chunk": round(t_rdt, 3),
                                "max_abs_diff_vs_gpu_pi": float((got - ref).abs().max())}
         if args.workload == "full":
             res["cpu_baseline"].update({"max_abs_diff_vs_gpu_chain": chain_diff,
-                                        "chain_parity_note": "a_hat of episode 0: GPU RDT-1B bf16 chunk (B=%d) -> slice -> predict vs oracle chunk -> oracle predict, "
-                                                             "same start noise and SDE noise; north-star tolerance 1e-2 (flat)" % B,
+                                        "chain_parity_note": "a_hat, worst of episodes %s: GPU RDT-1B bf16-model chunk (B=%d) -> slice -> predict vs oracle chunk -> oracle predict, "
+                                                             "same start noise and SDE noise; north-star tolerance 1e-2 (flat); per-episode figures and the timm==1.0.3 variance-RmsNorm "
+                                                             "chain in `parity`" % (sorted({0, B - 1}), B),
+                                        "parity": parity,
                                         "max_abs_diff_vs_gpu_rdt": rdt_diff, "rdt_output_scale": rdt_scale,
                                         "rdt_parity_note": "GPU batch row 0 (bf16 model, %s activations, B=%d, fp32 hand-over) vs oracle fp32 on the same bf16-rounded weights / "
-                                                           "inputs / start noise" % (args.rdt_compute, B)})
+                                                           "inputs / start noise" % (rdt_used, B)})
     if rank == 0:
         print(json.dumps(res))
     if dist is not None:

@@ -174,6 +174,7 @@ size_t vt_dino_workspace_bytes(vt_dino_t h, int B_total, int res);
  * over, and the CLS-only last block, run fc1 on the small-M packed-weight tile.  Replaces nothing in the reference (a layout of its nn.Linear weights). */
 size_t vt_dino_packed_bytes(vt_dino_t h);
 int vt_dino_set_packed(vt_dino_t h, void* buf, vt_stream_t stream);
+int vt_dino_set_range_flag(vt_dino_t h, unsigned* word);      /* see vt_rdt_set_range_flag */
 /* imgs[ncams] device pointers; is_u8: uint8 pixels else fp32; nhwc: [B,H,W,3] else [B,3,H,W];
  * pre_scale: 1/255 when the caller passed a numpy array (visual_encoder.py:66) else 1;
  * norm_mode: 0 auto (reference behaviour), 1 force ImageNet-normalise, 2 never;
@@ -244,6 +245,24 @@ int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state);
 int vt_rdt_set_io_dtype(vt_rdt_t h, int io_dtype);
 size_t vt_rdt_packed_bytes(vt_rdt_t h);
 int vt_rdt_set_packed(vt_rdt_t h, void* buf, vt_stream_t stream);
+/* Range guard (round 6).  The reference executes RDT in bf16 (models/rdt_runner.py:47-60,160; models/rdt/model.py:124: 8 exponent bits); an engine created
+ * with desc.cdt = desc.adt = VT_F16 has 5.  `word` = ONE zero-initialised uint32 in device memory, owned by the caller, resident as long as the handle is used
+ * (NULL = detach).  The kernels of vt_rdt_sample / vt_rdt_forward OR bits into it — no extra launch, never cleared by the library, so it is sticky across calls
+ * and hipGraph replays; the caller reads it when it likes (after a stream synchronise) and re-zeroes it:
+ *   VT_RANGE_XN_SAT     the un-normalised 16-bit operand x * gain a residual Linear hands to the next Linear (csrc/vt_gemm_pw.hip) left the fp16 range and was clamped
+ *   VT_RANGE_NONFINITE  an x0 prediction / solver state (vt_rdt_sample) or an output element (vt_rdt_forward) is inf or NaN: every other 16-bit store of the path
+ *                       converts with v_cvt_f16_f32 (overflow -> inf), and inf / NaN propagate through every consumer (GEMMs, norms, softmax) into the fp32
+ *                       residual stream, so an overflow anywhere upstream — inputs and converted weights included — ends here
+ *   VT_RANGE_ATTN_EMPTY a cross-attention row whose probabilities summed to 0 or inf (all keys masked, or a degenerate score row); the row is written as zeros
+ *                       (torch's SDPA returns NaN for a fully masked row, models/rdt/blocks.py:116-123)
+ * vt_dino_set_range_flag: the same word for a DINOv2 / SigLIP handle — VT_RANGE_GATE_SAT: the gated SwiGLU product of dinov2-giant left the fp16 range and was clamped. */
+#ifndef VT_RANGE_XN_SAT
+#define VT_RANGE_XN_SAT 1u
+#define VT_RANGE_NONFINITE 2u
+#define VT_RANGE_GATE_SAT 4u
+#define VT_RANGE_ATTN_EMPTY 8u
+#endif
+int vt_rdt_set_range_flag(vt_rdt_t h, unsigned* word);
 /* RDT.forward: x_tokens [B][horizon+1][hidden] adt (adapted state + action tokens), freq [B] fp32, t = t_dev[B] or the
  * scalar t_host when t_is_scalar, lang_c [B][L][hidden] / img_c [B][img_len][hidden] adt (adapted, before position
  * embeddings), lang_mask [B][L] bytes (1 = valid) or NULL -> out [B][horizon][out_dim] adt. */

@@ -12,6 +12,7 @@ for p in (ROOT, os.path.join(ROOT, "vla-touch_amd")):
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "needs_reference: needs /root/reference (build container only)")
+    config.addinivalue_line("markers", "slow: long oracle episodes; still part of `-m gpu`, but collected LAST so that a time-limited run has finished every other parity test first")
 
 
 def _gpu_ready() -> bool:
@@ -29,6 +30,7 @@ def pytest_collection_modifyitems(config, items):
     skip_ref = pytest.mark.skip(reason="/root/reference absent (GPU box)")
     have_gpu = _gpu_ready()
     skip_gpu = pytest.mark.skip(reason="needs an MI355X and the built libvlatouch_hip.so (run `-m gpu` on the GPU box)")
+    items.sort(key=lambda it: 1 if "slow" in it.keywords else 0)        # stable: the slow sub-marker only moves a test to the end of the run
     for it in items:
         if "needs_reference" in it.keywords and not have_ref:
             it.add_marker(skip_ref)

@@ -260,6 +260,7 @@ def test_rdt_1b_batch32_activation_types_and_rmsnorm_forms_vs_oracle():
     assert errs[("f16", "var")] <= 2.5e-3 * s_var, errs
 
 
+@pytest.mark.slow
 def test_rdt_1b_50_steps_batch16(rdt1b):
     """BASELINE configs[2]: RDT-1B, 50 denoise steps, B=16 — determinism, batch invariance and row-0 parity against the oracle."""
     d = rdt_inputs(16, seed=23)
@@ -307,48 +308,53 @@ def test_rdt_chunk_feeds_pi_refine_vs_oracle():
     assert out.shape == (2, T, 10) and e < 1e-4, e
 
 
-@pytest.mark.parametrize("force_dim", [3, 64])
-def test_chained_rdt1b_bf16_chunk_feeds_pi_refine_batch32_vs_oracle(rdt1b, force_dim):
-    """BASELINE configs[3] END TO END in the low-precision mode, the quantity the north-star tolerance is stated on: B = 32, RDT-1B bf16 chunk
-    (5-step DPM-Solver++) -> first 16 ticks x 10 EEF dims (`slice_cast`) -> DiffusionController.predict (DINOv2-base, T = 16, injected SDE noise)
-    = a_hat, exactly as bench.py's step chains them (frank_inference_eef.py:495-533, bridge_controller.py:149-182), against
-    oracle.rdt.predict_action -> oracle.controller.predict (fp32 math on the same bf16-rounded RDT weights / inputs / start noise) on episodes 0
-    and 31.  force_dim = 64: the 64-d tactile vector of BASELINE.json's workload (bridge_controller.py:25).
+def _rdt1b_runner(compute, rms):
+    """A second RDT-1B runner on the seed-7 weights of the `rdt1b` fixture with another activation type / RmsNorm form (2.4 GB + packed copies: callers drop it)."""
+    from models.rdt_runner import RDTRunner
+    from vlatouch import synth
+    cfg = {"rdt": {"hidden_size": 2048, "depth": 28, "num_heads": 32, "rms_norm": rms}, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_gelu",
+           "state_adaptor": "mlp3x_gelu",
+           "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": 5, "beta_schedule": "squaredcos_cap_v2",
+                               "prediction_type": "sample", "clip_sample": False}}
+    r = RDTRunner(action_dim=128, pred_horizon=64, config=cfg, lang_token_dim=4096, img_token_dim=1152, state_token_dim=128, max_lang_cond_len=1024,
+                  img_cond_len=4374, dtype=torch.bfloat16, device=DEV, init_weights=False, compute_dtype=compute)
+    r.load_state_dict(synth.fill_state_dict_device(synth.rdt_runner_shapes(**RDT1B), torch.device(DEV), torch.bfloat16, seed=7), assign=True)
+    return r
 
-    Normalisation statistics (controller_dataset.py:222-229 computes them FROM the data they normalise):
-      * "unit"     = the bench's: a_hat in the chunk's own units;                                              FLAT bar 1e-2 on a_hat
-      * "covering" = non-trivial: vla_mins / vla_maxs = the per-dimension range of this batch's chunks (what a dataset statistic is), expert
-                     action range from the non-trivial fixture (0.5 .. 2.0 wide, offset);                      FLAT bar 1e-2 on a_hat
-      * "narrow"   = the fixture's own vla range (0.4 .. 2.1 wide around -0.3), which does NOT cover an RDT-1B chunk of scale 1.7: |x_n| reaches 6 and
-                     the reference's own arithmetic multiplies any chunk error by action_range / vla_range (up to 3.0) on the way to a_hat, whose
-                     scale is then ~8 — beyond what bf16 resolves to 1e-2 (one bf16 ulp at 8 is 3e-2).  Bar: 1e-2 x that gain (+ the pi_I leg)."""
+
+def _chain(r, d, force_dim, rows, kinds, tag, bf16_state_too=False):
+    """BASELINE configs[3] END TO END in the low-precision mode at B = 32: runner `r`'s RDT-1B chunk (5-step DPM-Solver++) -> first 16 ticks x 10 EEF dims
+    (`slice_cast`) -> DiffusionController.predict (DINOv2-base, T = 16, injected SDE noise) = a_hat, exactly as bench.py's step chains them
+    (frank_inference_eef.py:495-533, bridge_controller.py:149-182), against oracle.rdt.predict_action -> oracle.controller.predict (fp32 math on the same
+    bf16-rounded RDT weights / inputs / start noise, the runner's RmsNorm form) on the episodes `rows`.  Returns ({stats kind: worst |a_hat - oracle|}, bars)."""
     from oracle import controller as oc
     from residual_controller.bridge_controller import DiffusionController
     from vlatouch import ops as _ops, _lib as L
     B, T = 32, 16
-    d = rdt_inputs(B, seed=29)
-    rdt1b.num_inference_timesteps = 5
+    r.num_inference_timesteps = 5
     g = np.random.default_rng(31 + force_dim)
     mk = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(np.float32)))
     cam1, cam2 = mk(0.2 + 0.8 * g.random((B, 3, 224, 224))), mk(0.6 * g.random((B, 3, 224, 224)))
     state, forces = mk(g.standard_normal((B, 10))), mk(g.standard_normal((B, force_dim)))
     z = mk(g.standard_normal((10, B, T, 10)))
     ctrl = cases.build_controller(DiffusionController, precision="bf16", device=DEV, size="base", stats_kind="nontrivial", force_dim=force_dim)
-    predict_chunk = lambda: rdt1b.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=d["x0"], return_fp32=True)
+    predict_chunk = lambda: r.predict_action(d["lang"], d["mask"], d["img"], d["state"], d["amask"], d["freq"], x_init=d["x0"], return_fp32=True)
     chunk = predict_chunk()
-    eng = rdt1b.engine()
-    try:      # the reference's own rounding points (bf16 solver state, rdt_runner.py:160), for the record
-        L.check(L.lib().vt_rdt_set_state_precision(eng._h, 0), "state precision")
-        chunk_bf16_state = predict_chunk().float().cpu()
-    finally:
-        L.lib().vt_rdt_set_state_precision(eng._h, int(eng.solver_state == "fp32"))
+    chunk_bf16_state = None
+    if bf16_state_too:
+        eng = r.engine()
+        try:      # the reference's own rounding points (bf16 solver state, rdt_runner.py:160), for the record
+            L.check(L.lib().vt_rdt_set_state_precision(eng._h, 0), "state precision")
+            chunk_bf16_state = predict_chunk().float().cpu()
+        finally:
+            L.lib().vt_rdt_set_state_precision(eng._h, int(eng.solver_state == "fp32"))
     vla = _ops.slice_cast(chunk, T, 10)
     assert vla.shape == (B, T, 10) and vla.dtype == torch.float32
     dev = lambda t: t.to(DEV)
     nt = cases.stats("nontrivial")
     lo, hi = vla.amin(dim=(0, 1)).cpu(), vla.amax(dim=(0, 1)).cpu()
     covering = dict(nt, vla_mins=lo, vla_maxs=hi, vla_range=hi - lo)
-    stats = {"unit": cases.stats("unit"), "covering": covering, "narrow": nt}
+    stats = {k: v for k, v in {"unit": cases.stats("unit"), "covering": covering, "narrow": nt}.items() if k in kinds}
     gain = float((nt["action_range"][:9] / nt["vla_range"][:9]).max())                 # dim 9 of the fixture has a zero vla range (the < 1e-6 guard)
     bars = {"unit": 1e-2, "covering": 1e-2, "narrow": 1e-2 * gain + 2e-3}
     got = {}
@@ -358,12 +364,13 @@ def test_chained_rdt1b_bf16_chunk_feeds_pi_refine_batch32_vs_oracle(rdt1b, force
         assert got[kind].shape == (B, T, 10) and torch.isfinite(got[kind]).all()
     sds = (cases.dino_sd("base"), cases.state_encoder_sd(2 * 768 + 10 + force_dim), cases.si_net_sd("ema"))
     worst = {k: 0.0 for k in stats}
-    for b in (0, 31):
-        ref_chunk = _oracle_episode(rdt1b, d, b, 5)                              # [64, 128] fp32
+    for b in rows:
+        ref_chunk = _oracle_episode(r, d, b, 5)                              # [64, 128] fp32
         e_chunk = float((chunk[b].float().cpu() - ref_chunk).abs().max())
-        e_chunk_bf = float((chunk_bf16_state[b] - ref_chunk).abs().max())
-        print(f"[chain bf16 B=32 force_dim {force_dim} row {b}] chunk err {e_chunk:.3e} with the fp32 solver state, {e_chunk_bf:.3e} with the reference's bf16 "
-              f"rounding points (chunk scale {float(ref_chunk.abs().max()):.2f})")
+        extra = ""
+        if chunk_bf16_state is not None:
+            extra = f", {float((chunk_bf16_state[b] - ref_chunk).abs().max()):.3e} with the reference's bf16 rounding points"
+        print(f"[chain {tag} B=32 force_dim {force_dim} row {b}] chunk err {e_chunk:.3e} with the fp32 solver state{extra} (chunk scale {float(ref_chunk.abs().max()):.2f})")
         one = slice(b, b + 1)
         for kind, st in stats.items():
             ref = oc.predict(sds[0], 12, sds[1], sds[2], st, state[one], ref_chunk[None, :T, :10], cam1[one], cam2[one], forces[one], z[:, one])
@@ -375,7 +382,66 @@ def test_chained_rdt1b_bf16_chunk_feeds_pi_refine_batch32_vs_oracle(rdt1b, force
             e_pi = float((pi_only[b] - ref[0]).abs().max())
             e = float((got[kind][b] - ref[0]).abs().max())
             worst[kind] = max(worst[kind], e)
-            print(f"[chain bf16 B=32 force_dim {force_dim} row {b} stats {kind}] pi_I alone {e_pi:.3e}  a_hat chained {e:.3e}  (a_hat scale "
+            print(f"[chain {tag} B=32 force_dim {force_dim} row {b} stats {kind}] pi_I alone {e_pi:.3e}  a_hat chained {e:.3e}  (a_hat scale "
                   f"{float(ref.abs().max()):.2f}, bar {bars[kind]:.2e})")
-    for kind in stats:
+    return worst, bars
+
+
+@pytest.mark.parametrize("force_dim", [3, 64])
+def test_chained_rdt1b_bf16_chunk_feeds_pi_refine_batch32_vs_oracle(rdt1b, force_dim):
+    """The quantity the north-star tolerance is stated on (a_hat of the chained path, `_chain`), the product default (compute_dtype="auto" = IEEE fp16 activations
+    under the range guard, mean-square RmsNorm), episodes 0 and 31.  force_dim = 64: the 64-d tactile vector of BASELINE.json's workload (bridge_controller.py:25).
+
+    Normalisation statistics (controller_dataset.py:222-229 computes them FROM the data they normalise):
+      * "unit"     = the bench's: a_hat in the chunk's own units;                                              FLAT bar 1e-2 on a_hat
+      * "covering" = non-trivial: vla_mins / vla_maxs = the per-dimension range of this batch's chunks (what a dataset statistic is), expert
+                     action range from the non-trivial fixture (0.5 .. 2.0 wide, offset);                      FLAT bar 1e-2 on a_hat
+      * "narrow"   = the fixture's own vla range (0.4 .. 2.1 wide around -0.3), which does NOT cover an RDT-1B chunk of scale 1.7: |x_n| reaches 6 and
+                     the reference's own arithmetic multiplies any chunk error by action_range / vla_range (up to 3.0) on the way to a_hat, whose
+                     scale is then ~8 — beyond what bf16 resolves to 1e-2 (one bf16 ulp at 8 is 3e-2).  Bar: 1e-2 x that gain (+ the pi_I leg)."""
+    d = rdt_inputs(32, seed=29)
+    worst, bars = _chain(rdt1b, d, force_dim, (0, 31), ("unit", "covering", "narrow"), "f16 act / meansq", bf16_state_too=True)
+    assert rdt1b.compute_dtype == torch.float16 and rdt1b.overflowed() == 0        # the range guard stayed clean: "auto" kept fp16
+    for kind in worst:
         assert worst[kind] <= bars[kind], (kind, worst[kind], bars[kind])
+
+
+def test_chained_rdt1b_var_rmsnorm_vs_oracle():
+    """The chained a_hat in the arithmetic released RDT-1B checkpoints need: timm==1.0.3's variance `RmsNorm` (models/rdt/blocks.py:22,150-156: hand-off with row
+    sums, online softmax in the cached cross-attention), fp16 activations.  Inputs = seed 17, episode 0: the oracle episode of
+    test_rdt_1b_batch32_activation_types_and_rmsnorm_forms_vs_oracle is reused (_ORACLE_CACHE), so this leg costs the pi_I oracle only.  FLAT bar 1e-2."""
+    r = _rdt1b_runner("auto", "var")
+    try:
+        d = rdt_inputs(32, seed=17)
+        worst, bars = _chain(r, d, 3, (0,), ("unit", "covering"), "f16 act / var")
+        assert r.compute_dtype == torch.float16 and r.overflowed() == 0
+        for kind in worst:
+            assert worst[kind] <= 1e-2, (kind, worst[kind])
+    finally:
+        del r
+        torch.cuda.empty_cache()
+
+
+BF16_CHAIN = {}
+
+
+def test_chained_rdt1b_bf16_activations_measured():
+    """The same chain with the reference's own execution dtype for the activations (compute_dtype="bf16"), seed 29 / episodes 0 and 31 (oracle episodes cached by
+    the default-dtype test above): measured and recorded for the strict-xfail test below; held only to 2e-2 here (what round 4 shipped)."""
+    r = _rdt1b_runner("bf16", "meansq")
+    try:
+        d = rdt_inputs(32, seed=29)
+        worst, _ = _chain(r, d, 3, (0, 31), ("unit", "covering"), "bf16 act / meansq")
+        BF16_CHAIN.update(worst)
+        for kind in worst:
+            assert worst[kind] <= 2e-2, (kind, worst[kind])
+    finally:
+        del r
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.xfail(strict=True, reason="bf16 ACTIVATIONS miss the north star's flat 1e-2 on the chained a_hat at RDT-1B (28 blocks x 5 steps of bf16 rounding: 1.0 - 1.4e-2) — "
+                                       "the reason the product's default computes in IEEE fp16 under the range guard (DESIGN.md section 3); if this ever passes, revisit the default")
+def test_chained_rdt1b_bf16_activations_meet_the_flat_bar():
+    assert BF16_CHAIN, "test_chained_rdt1b_bf16_activations_measured must run first (same module, collected above)"
+    assert max(BF16_CHAIN.values()) <= 1e-2, BF16_CHAIN

@@ -37,7 +37,7 @@ RUNNER_CFG = {"rdt": None, "lang_adaptor": "mlp2x_gelu", "img_adaptor": "mlp2x_g
 
 
 def make_runner(cfg, dtype, compute=None, **over):
-    """compute: the 16-bit activation type of a bf16 runner ("f16" = the default, "bf16" = the reference's execution dtype)."""
+    """compute: the 16-bit activation type of a bf16 runner (None = "auto": fp16 under the range guard; "f16" / "bf16" pin it; "bf16" = the reference's execution dtype)."""
     from models.rdt_runner import RDTRunner
     c = dict(RUNNER_CFG)
     c["rdt"] = {"hidden_size": cfg["hidden"], "depth": cfg["depth"], "num_heads": cfg["heads"]}
@@ -273,7 +273,7 @@ def test_cross_attention_fixed_maximum_matches_online_softmax(B):
     q / k norm gains scaled so that the bound exceeds 40 the launcher must fall back to the online form (bit-equal to it)."""
     from vlatouch import _lib as L
     cfg = cases.RDT_WIDE
-    r = make_runner(cfg, torch.bfloat16)
+    r = make_runner(cfg, torch.bfloat16, compute="bf16")        # bf16 probabilities: bounds up to 40 (fp16 ones: up to 10, tests/test_gpu_range_guard.py)
     ri = {k: v.to("cuda:0") for k, v in cases.rdt_inputs(cfg, B, 20, seed=5, dtype=torch.bfloat16).items()}
     args = (ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"])
     lib = L.lib()

@@ -197,7 +197,10 @@ __global__ __launch_bounds__(512) void attn_kvt_kernel(const VtAttnKvtParams p) 
     if (g == 0) { W[64] = m_run; W[65] = l; }
     return;
   }
-  const float inv = 1.0f / l;
+  // a row whose probabilities sum to 0 (every key masked; or every P flushed to zero) or to inf has no softmax: zeros + the range-guard bit instead of 0 / 0 = NaN actions
+  const bool l_bad = !(l > 0.f) || vt_nonfinite(l);
+  const float inv = l_bad ? 0.f : 1.0f / l;
+  if (l_bad && q < p.Nq) vt_range_note(p.range_flag, VT_RANGE_ATTN_EMPTY);
   if (q < p.Nq) {
     uint16_t* O = reinterpret_cast<uint16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
 #pragma unroll
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
   const float cscale = p.scale * 1.4426950408889634f;
   // FIXED: the bound is already in scaled-score units.  IEEE fp16 probabilities have 5 exponent bits: exp(s - B) in (e^-2B, 1] would sit in (and below)
   // the subnormals for every row whose largest score is well under the bound, so the fp16 form shifts the exponent up by 15 octaves (P in (2^15 e^-2B, 2^15],
-  // the largest finite fp16 is 65504): the row sum l carries the same factor and O / l cancels it; the launcher admits bounds up to 16 only (40 for bf16)
+  // the largest finite fp16 is 65504): the row sum l carries the same factor and O / l cancels it; the launcher admits bounds up to 10 only (P stays a normal fp16 number; 40 for bf16)
   constexpr float P_SHIFT = std::is_same<T, half_t>::value ? 15.0f : 0.0f;
   const float fixed_mc = p.fixed_max * 1.4426950408889634f - P_SHIFT;
   float4_t lacc = {0.f, 0.f, 0.f, 0.f};                           // row sums of P on the matrix pipe (every row of the tile = l)
@@ -411,7 +414,10 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
     if (g == 0) { W[64] = m_run; W[65] = l; }
     return;
   }
-  const float inv = 1.0f / l;
+  // a row whose probabilities sum to 0 (every key masked; or every P flushed to zero) or to inf has no softmax: zeros + the range-guard bit instead of 0 / 0 = NaN actions
+  const bool l_bad = !(l > 0.f) || vt_nonfinite(l);
+  const float inv = l_bad ? 0.f : 1.0f / l;
+  if (l_bad && q < p.Nq) vt_range_note(p.range_flag, VT_RANGE_ATTN_EMPTY);
   if (q < p.Nq) {
     uint16_t* O = reinterpret_cast<uint16_t*>(p.O) + (long)b * p.o_bs + (long)q * p.o_rs + h * 64;
 #pragma unroll
@@ -427,7 +433,7 @@ __global__ __launch_bounds__(512) void attn_kvt_ring_kernel(const VtAttnKvtParam
 // merge the key-range parts of a (batch, head): O = sum_p e^{(m_p - m) c} o_p / sum_p e^{(m_p - m) c} l_p, c = scale*log2(e) (exp2 domain, as above)
 template <typename T>
 __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_ws, uint16_t* __restrict__ O, long o_bs, long o_rs, int H, int Nq, int rows_pad,
-                                                          int parts, float cscale) {
+                                                          int parts, float cscale, unsigned* range_flag) {
   // one thread per (row, group of 4 d): 16 rows x 16 groups per block, grid.x blocks of 16 rows (at batch 1 a single block per (b, h) walked
   // 67 x 16 items serially: 38 us per call, 2.6 ms of the 31 ms robot step)
   const int b = blockIdx.z, h = blockIdx.y;
@@ -459,7 +465,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
     l += f * lp[pi];
     acc[0] += f * oa[pi].x; acc[1] += f * oa[pi].y; acc[2] += f * ob[pi].x; acc[3] += f * ob[pi].y;
   }
-  const float inv = 1.0f / l;
+  const bool l_bad = !(l > 0.f) || vt_nonfinite(l);
+  const float inv = l_bad ? 0.f : 1.0f / l;
+  if (l_bad) vt_range_note(range_flag, VT_RANGE_ATTN_EMPTY);
   uint2 t;
   t.x = kvt_pk<T>(acc[0] * inv, acc[1] * inv);
   t.y = kvt_pk<T>(acc[2] * inv, acc[3] * inv);
@@ -564,7 +572,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
   static const int ring = [] { const char* e = getenv("VLATOUCH_ATTN_RING"); return e ? atoi(e) : 5; }();
   // fixed-maximum softmax (see attn_kvt_ring_kernel): only with a finite load-time bound small enough that exp(-2B) stays a normal number
   attn_env_once();
-  const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= (f16 ? 16.f : 40.f);
+  // (IEEE fp16 probabilities: P = 2^15 exp(s - B) in [2^15 e^-2B, 2^15] must stay a NORMAL fp16 (>= 2^-14) for every admissible score, i.e. e^-2B >= 2^-29, B <= 10.05 —
+  // with the bound at 16 a row whose scores all sit ~27 under it flushed every P to zero (l = 0 -> NaN) and rows 20 under it lost their tail to subnormals)
+  const bool fixed = g_vt_attn_fixed && ring == 5 && p.fixed_max > 0.f && p.fixed_max <= (f16 ? 10.f : 40.f);
   // A/B: extra (unused) dynamic LDS per block lowers the blocks per CU from 4 (4 x 40 KiB = the whole CU) so that a GEMM block of the other in-flight
   // batch can share the CU (VLATOUCH_ATTN_LDS_PAD bytes: 13000 -> 3 blocks, 40000 -> 2 blocks)
   static const int lds_pad = [] { const char* e = getenv("VLATOUCH_ATTN_LDS_PAD"); return e ? atoi(e) : 0; }();
@@ -584,9 +594,9 @@ int vt_attn_kvt_launch(const VtAttnKvtParams& p, hipStream_t s) {
     if (qblocks != 1 || !p.part_ws || p.parts > 16) return VT_ERR_ARG;
     VT_KVT_GO(dim3(p.parts, p.H, p.B));
     if (f16) hipLaunchKernelGGL(attn_combine_kernel<half_t>, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (uint16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
-                                p.scale * 1.4426950408889634f);
+                                p.scale * 1.4426950408889634f, p.range_flag);
     else hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3((p.Nq + 15) / 16, p.H, p.B), dim3(256), 0, s, p.part_ws, (uint16_t*)p.O, p.o_bs, p.o_rs, p.H, p.Nq, nw * 16, p.parts,
-                            p.scale * 1.4426950408889634f);
+                            p.scale * 1.4426950408889634f, p.range_flag);
     return vt_check_launch();
   }
   dim3 grid(qblocks, p.H, p.B);

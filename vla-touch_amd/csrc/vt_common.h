@@ -191,4 +191,17 @@ template <> __device__ __forceinline__ void stf<float>(float* p, size_t i, float
 template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, size_t i, float v) { p[i] = f2bf(v); }
 template <> __device__ __forceinline__ void stf<half_t>(half_t* p, size_t i, float v) { p[i] = f2h(v); }
 
+// (bit values: include/vlatouch.h)
+#ifndef VT_RANGE_XN_SAT
+#define VT_RANGE_XN_SAT 1u
+#define VT_RANGE_NONFINITE 2u
+#define VT_RANGE_GATE_SAT 4u
+#define VT_RANGE_ATTN_EMPTY 8u
+#endif
+// sticky range-guard word of an engine (include/vlatouch.h: vt_rdt_set_range_flag): kernels OR bits in where a value left the 16-bit type's range; rare, relaxed, no return value
+__device__ __forceinline__ void vt_range_note(unsigned* flag, unsigned bit) {
+  if (flag) __hip_atomic_fetch_or(flag, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool vt_nonfinite(float v) { return !(fabsf(v) <= 3.4028234664e38f); }      // inf or NaN
+
 static inline int vt_check_launch() { return hipGetLastError() == hipSuccess ? VT_OK : VT_ERR_LAUNCH; }

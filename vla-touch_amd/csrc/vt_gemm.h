@@ -52,4 +52,6 @@ struct VtGemmParams {
   // blocks) at the top of this launch's epilogue, so that they stream HBM -> Infinity Cache under its store drain and the kernel boundary instead of at the
   // head of the next launch's k-loop.  Null = none.  Results do not depend on it.
   const void* pf_ptr; size_t pf_bytes;
+  // range guard (include/vlatouch.h, vt_rdt_set_range_flag): device word the hand-off producer ORs VT_RANGE_XN_SAT into when it clamps; null = none
+  unsigned* range_flag;
 };

@@ -341,7 +341,11 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
           // x * gain is NOT normalised yet (the consumer applies rstd): in IEEE fp16 a residual-stream outlier could leave the range — saturate instead of inf
           constexpr float LIM = std::is_same<T16, half_t>::value ? 65504.0f : 3.0e38f;
           auto sat = [](float v) { return fminf(fmaxf(v, -LIM), LIM); };
-          T16 ov[4] = {Elem<T16>::from_f(sat(o[0] * g4.x)), Elem<T16>::from_f(sat(o[1] * g4.y)), Elem<T16>::from_f(sat(o[2] * g4.z)), Elem<T16>::from_f(sat(o[3] * g4.w))};
+          const float xg[4] = {o[0] * g4.x, o[1] * g4.y, o[2] * g4.z, o[3] * g4.w};
+          if constexpr (std::is_same<T16, half_t>::value) {      // range guard: the clamp is not silent (vt_rdt_set_range_flag; compute_dtype="auto" re-runs in bf16)
+            if (fmaxf(fmaxf(fabsf(xg[0]), fabsf(xg[1])), fmaxf(fabsf(xg[2]), fabsf(xg[3]))) > LIM) vt_range_note(p.range_flag, VT_RANGE_XN_SAT);
+          }
+          T16 ov[4] = {Elem<T16>::from_f(sat(xg[0])), Elem<T16>::from_f(sat(xg[1])), Elem<T16>::from_f(sat(xg[2])), Elem<T16>::from_f(sat(xg[3]))};
           vt_epi_st64(Xn + (long)m * p.xn_ld + n, *reinterpret_cast<const uint2*>(ov));
         }
         if (c4 == 0 && m < p.M) *reinterpret_cast<float2*>(p.xn_part + ((long)m * pn + pcol) * 2) = make_float2(q, q1);

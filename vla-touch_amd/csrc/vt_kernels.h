@@ -42,6 +42,7 @@ struct VtAttnKvtParams {
   float* part_ws;             // [B][H][parts][16*NW rows][66] floats
   float fixed_max;            // > 0: an upper bound of |q . k| * scale known at load time (per-head RMS-normed q and k) -> fixed-maximum softmax; 0 = online
   int dtype;                  // VT_BF16 (or 0) / VT_F16: the 16-bit type of Q, the tile stream and O
+  unsigned* range_flag;       // range guard word (include/vlatouch.h): VT_RANGE_ATTN_EMPTY when a row's probabilities sum to 0 / inf (the row is written as zeros); null = none
 };
 // bytes of part_ws for vt_attn_kvt_launch with `parts` parts
 inline size_t vt_attn_kvt_part_bytes(int B, int H, int Nq, int parts) { return parts > 1 ? (size_t)B * H * parts * ((Nq + 15) / 16 * 16 + 16) * 66 * 4 : 0; }
@@ -58,8 +59,9 @@ int vt_k_retile_kv(const void* Ksrc, const void* Vsrc, long ld, void* KV, int M,
 int vt_gemm_launch(const VtGemmParams& p, hipStream_t s);
 int vt_attn_launch(const VtAttnParams& p, hipStream_t s);
 
+// range_flag (optional): VT_RANGE_NONFINITE when a row's statistics are inf / NaN (the final norm of a ViT tower)
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
-                 float eps, int mode, hipStream_t s);
+                 float eps, int mode, hipStream_t s, unsigned* range_flag = nullptr);
 int vt_k_headnorm(void* x, int dt, long tok_stride, int heads, long tokens, const float* w, float eps, int mode, hipStream_t s);
 int vt_k_groupnorm(const VtGnParams& p, hipStream_t s);
 // out = residual + colscale * act(sum of S fp32 split-K slabs [S][M][N] + bias); residual has the output dtype
@@ -72,7 +74,7 @@ int vt_k_slab_reduce(const float* slabs, int S, long slab_stride, int M, int N, 
                      const void* residual, long ldr, void* out, int odt, long ldo, const float* hn_w0, const float* hn_w1, int hn_c0, int hn_c1,
                      float hn_eps, int hn_mode, hipStream_t s, const void* pf_ptr = nullptr, size_t pf_bytes = 0);
 int vt_k_sinusoid(const float* t, float t_host, void* out, int odt, int B, int dim, int nets, long net_stride, int rdt_style, hipStream_t s);
-int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s);       // h[r][c] = silu(h[r][c]) * h[r][F + c], c < F, in place
+int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s, unsigned* range_flag = nullptr);       // h[r][c] = silu(h[r][c]) * h[r][F + c], c < F, in place
 int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ldo, int rows, int cols, int act, hipStream_t s);
 int vt_k_sde_update(float* x, const float* v, const float* sc, const float* z, long n, float dt, float gi, float gdg, float eps,
                     float noise_scale, float d, float score_eps, int backward, hipStream_t s);

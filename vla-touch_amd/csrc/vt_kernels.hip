@@ -15,7 +15,7 @@ namespace {
 template <typename TI, typename TO, int MAXV>
 __global__ __launch_bounds__(256) void rownorm_kernel(const TI* __restrict__ x, long ldx, TO* __restrict__ y, long ldy,
                                                       const float* __restrict__ w, const float* __restrict__ b,
-                                                      int rows, int D, float eps, int mode) {
+                                                      int rows, int D, float eps, int mode, unsigned* range_flag) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const TI* __restrict__ x, 
     var = (mode == VT_NORM_RMS_VAR) ? q / (float)(D - 1) : q / (float)D;
     if (mode == VT_NORM_RMS_VAR) mean = 0.f;   // timm<=1.0.8 rms_norm: x * rsqrt(var_unbiased(x) + eps), x not centred
   }
+  if (range_flag && lane == 0 && vt_nonfinite(var)) vt_range_note(range_flag, VT_RANGE_NONFINITE);
   const float rstd = rsqrtf(var + eps);
   TO* yr = y + (long)row * ldy;
 #pragma unroll
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const TI* __restrict__ x, 
 // blocks of the wave-per-row kernel for the [B*67, 2048] RMSNorms of the RDT step loop
 template <typename TO, int NV>
 __global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restrict__ x, long ldx, TO* __restrict__ y, long ldy, const float* __restrict__ w,
-                                                            const float* __restrict__ b, int D, float eps, int mode) {
+                                                            const float* __restrict__ b, int D, float eps, int mode, unsigned* range_flag) {
   __shared__ float red[8];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const float* xr = x + (long)blockIdx.x * ldx;
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restr
     var = (mode == VT_NORM_RMS_VAR) ? d2 / (float)(D - 1) : d2 / (float)D;
     if (mode == VT_NORM_RMS_VAR) mean = 0.f;
   }
+  if (range_flag && tid == 0 && vt_nonfinite(var)) vt_range_note(range_flag, VT_RANGE_NONFINITE);     // an inf / NaN anywhere in the row makes its statistics non-finite
   const float rstd = rsqrtf(var + eps);
   TO* yr = y + (long)blockIdx.x * ldy;
 #pragma unroll
@@ -138,7 +140,7 @@ __global__ __launch_bounds__(256) void rownorm_block_kernel(const float* __restr
 // __syncthreads() per row and keeps a quarter of the bytes in flight per CU; it stays for the few-row RMSNorms of the RDT step loop)
 template <typename TO, int NV>
 __global__ __launch_bounds__(256) void rownorm_wave_kernel(const float* __restrict__ x, long ldx, TO* __restrict__ y, long ldy, const float* __restrict__ w,
-                                                           const float* __restrict__ b, int rows, int D, float eps, int mode) {
+                                                           const float* __restrict__ b, int rows, int D, float eps, int mode, unsigned* range_flag) {
   const int lane = threadIdx.x & 63;
   const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(256) void rownorm_wave_kernel(const float* __restri
     var = (mode == VT_NORM_RMS_VAR) ? d2 / (float)(D - 1) : d2 / (float)D;
     if (mode == VT_NORM_RMS_VAR) mean = 0.f;
   }
+  if (range_flag && lane == 0 && vt_nonfinite(var)) vt_range_note(range_flag, VT_RANGE_NONFINITE);
   const float rstd = rsqrtf(var + eps);
   TO* yr = y + row * ldy;
 #pragma unroll
@@ -435,7 +438,7 @@ __global__ void act_copy_kernel(const TI* __restrict__ in, long ldi, TO* __restr
 
 // SwiGLU gate, in place: h[r][c] = silu(h[r][c]) * h[r][F + c] for c < F (rows of 2 F values; HF Dinov2SwiGLUFFN: x1, x2 = hidden.chunk(2)); 8 / 4 elements per thread
 template <typename T>
-__global__ void swiglu_kernel(T* __restrict__ h, long ld, long rows, int F) {
+__global__ void swiglu_kernel(T* __restrict__ h, long ld, long rows, int F, unsigned* range_flag) {
   constexpr int V = 16 / sizeof(T);
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int per_row = F / V;
@@ -452,7 +455,10 @@ __global__ void swiglu_kernel(T* __restrict__ h, long ld, long rows, int F) {
     float g = x1 * __builtin_amdgcn_rcpf(1.0f + fast_exp(-x1)) * x2;
     // IEEE fp16 storage (the low-precision DINOv2 mode): the gated product of two fp16 values can leave the fp16 range (outlier tokens of real giant
     // checkpoints); saturate instead of producing inf, which fc2 would turn into NaN for the whole row (inf - inf across the k range)
-    if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) g = fminf(fmaxf(g, -65504.0f), 65504.0f);
+    if constexpr (sizeof(T) == 2 && !std::is_same<T, bf16_t>::value) {
+      if (fabsf(g) > 65504.0f) vt_range_note(range_flag, VT_RANGE_GATE_SAT);      // the clamp is not silent (vt_dino_set_range_flag)
+      g = fminf(fmaxf(g, -65504.0f), 65504.0f);
+    }
     av[k] = Elem<T>::from_f(g);
   }
   *reinterpret_cast<uint4*>(p1) = a;
@@ -667,12 +673,12 @@ inline dim3 g1(long n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)
   if ((dt) == VT_F32) { using T = float; __VA_ARGS__; } else if ((dt) == VT_F16) { using T = half_t; __VA_ARGS__; } else { using T = bf16_t; __VA_ARGS__; }
 
 int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, const float* w, const float* b, int rows, int D,
-                 float eps, int mode, hipStream_t s) {
+                 float eps, int mode, hipStream_t s, unsigned* range_flag) {
   if (D % 4 || D > 64 * 4 * 8 || rows <= 0) return VT_ERR_ARG;
   static const int wave_rows = [] { const char* e = getenv("VLATOUCH_ROWNORM_WAVE"); return e ? atoi(e) : 8192; }();   // rows from which the wave-per-row kernel takes over (0 = never)
   if (xdt == VT_F32 && D >= 512 && wave_rows > 0 && rows >= wave_rows && (ldx % 4) == 0 && (ldy % 4) == 0) {
     const dim3 grid((unsigned)((rows + 3) / 4));
-#define VT_RNW(TO, NV) hipLaunchKernelGGL((rownorm_wave_kernel<TO, NV>), grid, dim3(256), 0, s, (const float*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode)
+#define VT_RNW(TO, NV) hipLaunchKernelGGL((rownorm_wave_kernel<TO, NV>), grid, dim3(256), 0, s, (const float*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode, range_flag)
 #define VT_RNW_T(TO) do { if (D <= 1024) VT_RNW(TO, 4); else if (D <= 1280) VT_RNW(TO, 5); else VT_RNW(TO, 8); } while (0)
     if (ydt == VT_F32) VT_RNW_T(float); else if (ydt == VT_F16) VT_RNW_T(half_t); else VT_RNW_T(bf16_t);
 #undef VT_RNW_T
@@ -680,15 +686,15 @@ int vt_k_rownorm(const void* x, int xdt, long ldx, void* y, int ydt, long ldy, c
     return vt_check_launch();
   }
   if (xdt == VT_F32 && D >= 512 && (rows >= 256 || D >= 1024) && (ldx % 4) == 0 && (ldy % 4) == 0) {    // block per row (also for few wide rows: latency)
-    if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode);
-    else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode);
-    else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode);
+    if (ydt == VT_F32) hipLaunchKernelGGL((rownorm_block_kernel<float, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (float*)y, ldy, w, b, D, eps, mode, range_flag);
+    else if (ydt == VT_F16) hipLaunchKernelGGL((rownorm_block_kernel<half_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (half_t*)y, ldy, w, b, D, eps, mode, range_flag);
+    else hipLaunchKernelGGL((rownorm_block_kernel<bf16_t, 2>), dim3(rows), dim3(256), 0, s, (const float*)x, ldx, (bf16_t*)y, ldy, w, b, D, eps, mode, range_flag);
     return vt_check_launch();
   }
   dim3 grid((rows + 3) / 4);
   DISPATCH_T(xdt, TI, DISPATCH_T(ydt, TO, {
-    if (D <= 1024) hipLaunchKernelGGL((rownorm_kernel<TI, TO, 4>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode);
-    else hipLaunchKernelGGL((rownorm_kernel<TI, TO, 8>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode);
+    if (D <= 1024) hipLaunchKernelGGL((rownorm_kernel<TI, TO, 4>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode, range_flag);
+    else hipLaunchKernelGGL((rownorm_kernel<TI, TO, 8>), grid, dim3(256), 0, s, (const TI*)x, ldx, (TO*)y, ldy, w, b, rows, D, eps, mode, range_flag);
   }))
   return vt_check_launch();
 }
@@ -746,10 +752,10 @@ int vt_k_act_copy(const void* in, int idt, long ldi, void* out, int odt, long ld
   return vt_check_launch();
 }
 
-int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s) {
+int vt_k_swiglu(void* h, int dt, long ld, long rows, int F, hipStream_t s, unsigned* range_flag) {
   const int V = (dt == VT_F32) ? 4 : 8;
   if (F % V || ld % V || rows <= 0) return VT_ERR_ARG;
-  DISPATCH_T(dt, T, hipLaunchKernelGGL((swiglu_kernel<T>), g1(rows * (F / V)), dim3(256), 0, s, (T*)h, ld, rows, F))
+  DISPATCH_T(dt, T, hipLaunchKernelGGL((swiglu_kernel<T>), g1(rows * (F / V)), dim3(256), 0, s, (T*)h, ld, rows, F, range_flag))
   return vt_check_launch();
 }
 

@@ -40,9 +40,15 @@ struct vt_dino_s {
   vt_dino_desc d;
   const void* patch_w; const float *patch_b, *cls_pos0, *lnf_w, *lnf_b;
   DinoLayer L[48];
+  unsigned* range_flag = nullptr;      // range guard word (vt_dino_set_range_flag)
 };
 
 int vt_dino_num_weights(const vt_dino_desc* d) { return 3 + 14 * d->layers + 2; }
+int vt_dino_set_range_flag(vt_dino_t h, unsigned* word) {
+  if (!h) return vt_fail(VT_ERR_ARG, "vt_dino_set_range_flag: null handle");
+  h->range_flag = word;
+  return VT_OK;
+}
 
 int vt_dino_create(const vt_dino_desc* desc, const void* const* w, int n, vt_dino_t* out) {
   if (!desc || !w || !out) return vt_fail(VT_ERR_ARG, "vt_dino_create: null argument");
@@ -165,7 +171,7 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
       p.Wp = swiglu ? nullptr : L.fc1_wp;
       if (p.Wp && vt_gemm_fast_eligible(p) && vt_gemm_pw_eligible(p)) p.Wp = nullptr;   // the 160 x 128 weights-in-registers tile is the RDT denoise loop's; ViT GEMMs stay on the persistent tile
       CK(vt_wrap(vt_gemm_launch(p, s), "dino fc1")); }
-    if (swiglu) CK(vt_wrap(vt_k_swiglu(ws + w.h1, d.adt, N1, rows, Dm, s), "dino swiglu gate"));
+    if (swiglu) CK(vt_wrap(vt_k_swiglu(ws + w.h1, d.adt, N1, rows, Dm, s, h->range_flag), "dino swiglu gate"));
     { VtGemmParams p = lin(ws + w.h1, d.adt, N1, L.fc2_w, d.cdt, Dm, L.fc2_b, tok, VT_F32, tok_stride, rows, D, Dm, VT_ACT_NONE);
       p.colscale = L.ls2; p.residual = tok; p.ldr = tok_stride;
       // a few images (2 x 257 rows at batch 1): 108 tiles of 64 x 64 would each walk K = 3072 alone (50 us); DINO_SPLITK slices per tile into fp32
@@ -226,8 +232,8 @@ int vt_dino_forward(vt_dino_t h, const void* const* imgs, int ncams, int is_u8, 
     CK(ffn(L, M, D));
   }
   // 3. final LayerNorm: on the CLS rows only -> pooler_output (DINOv2), or on every token -> last_hidden_state (SigLIP)
-  if (d.out_all) CK(vt_k_rownorm(tok, VT_F32, D, out, VT_F32, D, h->lnf_w, h->lnf_b, M, D, d.eps, VT_NORM_LAYER, s));
-  else CK(vt_k_rownorm(tok, VT_F32, (long)N * D, out, VT_F32, D, h->lnf_w, h->lnf_b, Bt, D, d.eps, VT_NORM_LAYER, s));
+  if (d.out_all) CK(vt_k_rownorm(tok, VT_F32, D, out, VT_F32, D, h->lnf_w, h->lnf_b, M, D, d.eps, VT_NORM_LAYER, s, h->range_flag));
+  else CK(vt_k_rownorm(tok, VT_F32, (long)N * D, out, VT_F32, D, h->lnf_w, h->lnf_b, Bt, D, d.eps, VT_NORM_LAYER, s, h->range_flag));
   return VT_OK;
 }
 

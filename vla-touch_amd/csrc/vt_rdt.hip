@@ -70,6 +70,7 @@ struct vt_rdt_s {
   const void *ffc1_wp, *ffc2_wp, *t_w1p, *t_w2p;      // + the small per-step Linears (timestep embedder, final projection; state adaptor: Adaptor::wp)
   int io_dt = VT_BF16;          // 16-bit modes: the grid the start noise (and, with state_f32 = 0, the solver state) is rounded to = the reference's dtype
   int state_f32 = 1;            // 16-bit modes: keep the solver state, the network's x0 output and the final projection in fp32 (vt_rdt_set_state_precision)
+  unsigned* range_flag = nullptr; // device word of the range guard (vt_rdt_set_range_flag), null = none
   float score_bound[64];        // per block: upper bound of |q . k| * scale in its cross-attention (vt_rdt_set_score_bounds), 0 = unknown
   Adaptor lang, img, state;
 };
@@ -129,6 +130,11 @@ int vt_rdt_set_score_bounds(vt_rdt_t h, const float* bounds, int n) {
 int vt_rdt_set_io_dtype(vt_rdt_t h, int io_dtype) {
   if (!h || (io_dtype != VT_BF16 && io_dtype != VT_F16)) return vt_fail(VT_ERR_ARG, "vt_rdt_set_io_dtype: bf16 or fp16");
   h->io_dt = io_dtype;
+  return VT_OK;
+}
+int vt_rdt_set_range_flag(vt_rdt_t h, unsigned* word) {
+  if (!h) return vt_fail(VT_ERR_ARG, "vt_rdt_set_range_flag: null handle");
+  h->range_flag = word;
   return VT_OK;
 }
 int vt_rdt_set_state_precision(vt_rdt_t h, int fp32_state) {
@@ -258,6 +264,7 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
           bool* hn_done = nullptr, const float* next_norm = nullptr, bool* xn_done = nullptr, bool pw_fuse = true) {
   if (hn_done) *hn_done = false;
   if (xn_done) *xn_done = false;
+  p.range_flag = c.h->range_flag;
   // (frozen, fragment-packed weights at small M: the split GEMM below runs on vt_gemm_pws.hip in its slab mode — p.Wp travels with q)
   const long tiles64 = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
   const int nk = p.K / 64;
@@ -419,6 +426,7 @@ int cross_attn(RCtx& c, int l, const uint8_t* lang_mask, int N) {
     p.B = c.B; p.H = d.heads; p.Nq = N; p.Nk = Lc; p.T = lpad64(c.B * Lc) / 64; p.scale = 0.125f;
     p.fixed_max = c.h->score_bound[l];
     p.dtype = d.adt;
+    p.range_flag = c.h->range_flag;
     if (c.w.attn_parts > 1 && Lc >= 64 * 2 * c.w.attn_parts) { p.parts = c.w.attn_parts; p.part_ws = (float*)(c.ws + c.w.attn_part); }
     return vt_wrap(vt_attn_kvt_launch(p, c.s), "rdt cross attention (cached K / Vt)");
   }
@@ -565,21 +573,30 @@ __global__ void build_sa_in_kernel(const float* __restrict__ noisy, const void* 
 }
 
 // x0 = out_tok[:, -horizon:, :]  (model.py:164) gathered contiguous
-__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_16) {      // is_16: both buffers 16-bit (a plain copy), else both fp32
+__global__ void take_actions_kernel(const void* out_tok, void* x0, int B, int N, int Hh, int S, int is_16, int dt16, unsigned* range_flag) {      // is_16: both buffers 16-bit (a plain copy), else both fp32; dt16: which 16-bit type
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
   const long r = i / S;
   const int t = (int)(r % Hh), b = (int)(r / Hh);
   const long src = ((long)b * N + (N - Hh) + t) * S + c;
-  if (is_16) ((uint16_t*)x0)[i] = ((const uint16_t*)out_tok)[src]; else ((float*)x0)[i] = ((const float*)out_tok)[src];
+  if (is_16) {
+    const uint16_t u = ((const uint16_t*)out_tok)[src];
+    ((uint16_t*)x0)[i] = u;
+    const uint16_t em = dt16 == VT_F16 ? 0x7C00 : 0x7F80;          // exponent all ones = inf / NaN
+    if ((u & em) == em) vt_range_note(range_flag, VT_RANGE_NONFINITE);
+  } else {
+    const float v = ((const float*)out_tok)[src];
+    ((float*)x0)[i] = v;
+    if (vt_nonfinite(v)) vt_range_note(range_flag, VT_RANGE_NONFINITE);
+  }
 }
 
 // noisy = round(a*noisy + b0*x0 + b1*x0_prev) ; last step: * mask   (rdt_runner.py:158-163).  x0_dt: storage type of the x0 buffers; round_dt: the
 // reference's `noisy_action.to(dtype)` after every step (VT_F32 = none: the solver state is kept in fp32); mask_dt: storage type of the action mask
 __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, const void* x0p, float a, float b0, float b1, const void* mask, int last,
                                   int B, int Hh, int S, int x0_dt, int round_dt, int mask_dt, int sample_pred, float alpha_s, float sigma_s, void* x0_store,
-                                  float* __restrict__ out) {
+                                  float* __restrict__ out, unsigned* range_flag) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)B * Hh * S) return;
   const int c = (int)(i % S);
@@ -591,6 +608,7 @@ __global__ void dpm_update_kernel(float* __restrict__ noisy, const void* x0, con
   if (x0p) v += b1 * ldx(x0p, i, x0_dt);
   v = rnd16(v, round_dt);                                           // `noisy_action.to(state_traj.dtype)` (rdt_runner.py:160)
   if (last) v = rnd16(v * ldx(mask, (long)b * S + c, mask_dt), round_dt);
+  if (vt_nonfinite(v)) vt_range_note(range_flag, VT_RANGE_NONFINITE);     // range guard: an overflow anywhere upstream arrives here as inf / NaN
   noisy[i] = v;
   if (out) out[i] = v;                                              // the last step also writes the caller's buffer
 }
@@ -630,7 +648,7 @@ int vt_rdt_forward(vt_rdt_t h, const void* x_tokens, const float* freq, const fl
   CK(vt_check_launch());
   CK(run_blocks(c, lang_mask));
   hipLaunchKernelGGL(take_actions_kernel, g1((long)B * d.horizon * d.out_dim), dim3(256), 0, c.s, (const void*)(c.ws + c.w.out_tok), out, B, N, d.horizon,
-                     d.out_dim, is16(dt) ? 1 : 0);
+                     d.out_dim, is16(dt) ? 1 : 0, dt, h->range_flag);
   return vt_check_launch();
 }
 
@@ -686,12 +704,12 @@ int vt_rdt_sample(vt_rdt_t h, const void* lang_tokens, const uint8_t* lang_mask,
                        h->x_pos, B, N, D, dt);
     CK(vt_check_launch());
     CK(run_blocks(c, lang_mask));
-    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, x0_dt != VT_F32 ? 1 : 0);
+    hipLaunchKernelGGL(take_actions_kernel, g1(n), dim3(256), 0, s, (const void*)(c.ws + c.w.out_tok), (void*)x0_cur, B, N, Hh, S, x0_dt != VT_F32 ? 1 : 0, dt, h->range_flag);
     CK(vt_check_launch());
     const float* cf = coef + 5 * k;
     const bool last = k == n_steps - 1;
     hipLaunchKernelGGL(dpm_update_kernel, g1(n), dim3(256), 0, s, (float*)(c.ws + c.w.noisy), (const void*)x0_cur, (const void*)(cf[2] != 0.f ? x0_prev : nullptr), cf[0], cf[1],
-                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, x0_dt, round_dt, dt, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr);
+                       cf[2], action_mask, last ? 1 : 0, B, Hh, S, x0_dt, round_dt, dt, sample_pred, cf[3], cf[4], (void*)(sample_pred ? nullptr : x0_cur), last ? out : (float*)nullptr, h->range_flag);
     CK(vt_check_launch());
     char* t = x0_cur; x0_cur = x0_prev; x0_prev = t;
   }

@@ -14,8 +14,9 @@ from typing import Dict, Optional
 
 import torch
 
+from vlatouch import _lib as L
 from vlatouch import synth
-from vlatouch.engine import SiglipEngine
+from vlatouch.engine import AutoRange, SiglipEngine
 from vlatouch.module import default_precision
 
 _SO400M = dict(hidden_size=1152, intermediate_size=4304, num_hidden_layers=27, num_attention_heads=16, image_size=384, patch_size=14)
@@ -72,7 +73,10 @@ class SiglipVisionTower:
                     "or set VLATOUCH_SYNTH_WEIGHTS=1 for deterministic synthetic weights (no network access here)")
         prec = self.precision
         if prec == "bf16":      # as for DINOv2: IEEE fp16 storage (fp32 residual stream) is the low-precision mode of the encoders
-            prec = os.environ.get("VLATOUCH_SIGLIP_PRECISION", "fp16")
+            prec = os.environ.get("VLATOUCH_SIGLIP_PRECISION") or "fp16"
+            if "VLATOUCH_SIGLIP_PRECISION" not in os.environ:      # range guard (round 6): the fp16 default falls back to bf16 storage when the engine flags a non-finite feature
+                self._range = AutoRange(f"SiglipVisionTower({self.vision_tower_name})")
+        self._sd_loaded = sd
         self.engine = SiglipEngine(sd, heads=self._cfg["num_attention_heads"], precision=prec, device=self._device,
                                    patch=self._cfg["patch_size"])
         self.vision_tower = self
@@ -88,11 +92,23 @@ class SiglipVisionTower:
             raise NotImplementedError("pooler_output (SigLIP attention-pooling head) is not on the RDT path and is not built")
         raise ValueError(f"Unexpected select feature: {self.select_feature}")
 
+    def _encode(self, x):
+        out = self.engine.forward(x)
+        rg = getattr(self, "_range", None)
+        if rg is not None and not rg.fell_back:
+            bits = rg.after(self.engine, self.engine.adt == L.F16)
+            if bits:
+                rg.fall_back(bits)
+                self.engine = SiglipEngine(self._sd_loaded, heads=self._cfg["num_attention_heads"], precision="bf16", device=self._device,
+                                           patch=self._cfg["patch_size"])
+                out = self.engine.forward(x)
+        return out
+
     @torch.no_grad()
     def forward(self, images):
         if isinstance(images, list):
-            return [self.feature_select(self.engine.forward(im.unsqueeze(0))).to(im.dtype) for im in images]
-        return self.feature_select(self.engine.forward(images)).to(images.dtype)
+            return [self.feature_select(self._encode(im.unsqueeze(0))).to(im.dtype) for im in images]
+        return self.feature_select(self._encode(images)).to(images.dtype)
 
     __call__ = forward
 

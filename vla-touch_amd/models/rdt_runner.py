@@ -23,6 +23,7 @@ import torch
 
 from vlatouch import synth
 from vlatouch.module import ParamModule
+from vlatouch.engine import AutoRange
 from vlatouch.rdt_engine import RdtEngine, adaptor_depth
 from models.rdt.model import RDT
 
@@ -77,11 +78,19 @@ class RDTRunner:
         # compute_dtype (extension): the engine's 16-bit activation / MFMA operand type for a bf16 model — torch.float16 (default: the bf16 weights convert
         # exactly, same width and MFMA rate, 3 more mantissa bits: |chunk - fp32 reference| 1e-2 -> 1.2e-3 at RDT-1B) or torch.bfloat16
         # (the reference's own execution dtype, rounding after every op).  config['rdt']['compute_dtype'] / VLATOUCH_RDT_COMPUTE = "f16" | "bf16".
-        cd = compute_dtype or config.get('rdt', {}).get('compute_dtype') or os.environ.get("VLATOUCH_RDT_COMPUTE", "f16")
+        # "auto" (default since round 6): start in fp16 under the engine's RANGE GUARD (vlatouch.engine.RangeGuard / AutoRange; include/vlatouch.h,
+        # vt_rdt_set_range_flag): weights that do not fit fp16 -> bf16 at load; a clamped hand-off operand or a non-finite x0 prediction on the first call
+        # (checked synchronously) or any later call (checked without blocking, one call of lag) -> a RuntimeWarning, the engine is rebuilt in bf16 — the
+        # reference's own execution dtype, rdt_runner.py:47-60,160, model.py:124 — and the call is repeated.  "f16" / "bf16" pin the type (the guard still
+        # records: `runner.engine().overflowed()`).
+        cd = compute_dtype or config.get('rdt', {}).get('compute_dtype') or os.environ.get("VLATOUCH_RDT_COMPUTE", "auto")
+        self._range = None
         if isinstance(cd, str):
-            if cd not in ("f16", "fp16", "float16", "bf16", "bfloat16"):
-                raise ValueError(f"compute_dtype must be 'f16' or 'bf16', got {cd!r}")
-            cd = torch.float16 if cd in ("f16", "fp16", "float16") else torch.bfloat16
+            if cd not in ("auto", "f16", "fp16", "float16", "bf16", "bfloat16"):
+                raise ValueError(f"compute_dtype must be 'auto', 'f16' or 'bf16', got {cd!r}")
+            if cd == "auto" and dtype == torch.bfloat16:
+                self._range = AutoRange("RDTRunner")
+            cd = torch.bfloat16 if cd in ("bf16", "bfloat16") else torch.float16
         self.compute_dtype = cd if dtype == torch.bfloat16 else dtype       # fp32 (and true fp16) models compute in their own dtype
         # precision of the sampler's state between network evaluations in the 16-bit mode (extension; RdtEngine): "fp32" (default) or the reference's "bf16"
         self.solver_state = solver_state or config.get('rdt', {}).get('solver_state') or os.environ.get("VLATOUCH_RDT_SOLVER_STATE", "fp32")
@@ -175,7 +184,37 @@ class RDTRunner:
                 lang_adaptor=self.config['lang_adaptor'], img_adaptor=self.config['img_adaptor'], state_adaptor=self.config['state_adaptor'],
                 dtype=self.compute_dtype, io_dtype=self.dtype, rms_mode=self.rms_mode, solver_state=self.solver_state, device=self.device)
             self._engine_key = key
+            rg = self._range
+            if rg is not None and not rg.fell_back and self.compute_dtype == torch.float16 and not self._engine.weight_absmax <= 65504.0:
+                # static side of the guard: a weight of the bf16 checkpoint does not fit IEEE fp16 (it converted to inf)
+                import warnings
+                warnings.warn(f"RDTRunner: max |weight| = {self._engine.weight_absmax:g} does not fit IEEE fp16; computing in bf16", RuntimeWarning, stacklevel=3)
+                rg.fell_back = True
+                self._to_bf16()
         return self._engine
+
+    def _to_bf16(self):
+        """The range guard's fallback: drop the fp16 engine (its 2.4 GB of converted weights first) and rebuild in the reference's bf16."""
+        self._engine = None
+        self.compute_dtype = torch.bfloat16
+        return self.engine()
+
+    def _guarded(self, call):
+        """Run `call(engine)`; under compute_dtype="auto" consult the engine's range guard afterwards and, if it fired, repeat the call in bf16."""
+        eng = self.engine()
+        out = call(eng)
+        rg = self._range
+        if rg is not None and not rg.fell_back:
+            bits = rg.after(eng, eng.dtype == torch.float16)
+            if bits:
+                rg.fall_back(bits)
+                del eng
+                out = call(self._to_bf16())
+        return out
+
+    def overflowed(self, clear: bool = False) -> int:
+        """Bits of the engine's sticky range-guard word (0 = every value stayed inside the 16-bit compute type; vlatouch._lib.RANGE_NAMES); synchronises."""
+        return self.engine().overflowed(clear=clear)
 
     # ---- inference
     def adapt_conditions(self, lang_tokens, img_tokens, state_tokens):
@@ -202,9 +241,9 @@ class RDTRunner:
         if x_init is None:
             x_init = self._draw_start(eng, B)
         with torch.no_grad():
-            return eng.sample(lang_cond, lang_attn_mask, img_cond, state_traj.reshape(B, -1), action_mask, ctrl_freqs, x_init,
-                              num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
-                              beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=True)
+            return self._guarded(lambda e: e.sample(lang_cond, lang_attn_mask, img_cond, state_traj.reshape(B, -1), action_mask, ctrl_freqs, x_init,
+                                                    num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
+                                                    beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=True))
 
     def _draw_start(self, eng, B):
         """The reference's `torch.randn(size=(B, horizon, action_dim), dtype=dtype)` start (rdt_runner.py:136): torch's generator, so
@@ -221,9 +260,10 @@ class RDTRunner:
         if x_init is None:
             x_init = self._draw_start(eng, B)
         with torch.no_grad():
-            return eng.sample(lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init,
-                              num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
-                              beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=False, return_fp32=return_fp32)
+            return self._guarded(lambda e: e.sample(lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init,
+                                                    num_inference_steps=self.num_inference_timesteps, num_train_timesteps=self.num_train_timesteps,
+                                                    beta_schedule=self.beta_schedule, prediction_type=self.prediction_type, adapted=False,
+                                                    return_fp32=return_fp32))
 
     def compute_loss(self, *a, **k):
         raise NotImplementedError("training is outside this build's scope (inference-only hot path)")

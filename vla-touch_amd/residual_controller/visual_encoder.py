@@ -23,7 +23,7 @@ import torch
 
 from vlatouch import _lib as L
 from vlatouch import synth
-from vlatouch.engine import DinoEngine
+from vlatouch.engine import AutoRange, DinoEngine
 from vlatouch.module import default_precision
 
 _SIZES = {  # visual_encoder.py:31-46
@@ -90,9 +90,15 @@ class DINOv2Encoder:
         # the low-precision mode of the ENCODER is IEEE fp16 (same MFMA rate as bf16, 3 more mantissa bits; the residual stream
         # stays fp32 so activations are range-safe): bf16 features alone cost 7e-3 on obs_cond, most of the 1e-2 budget on a_t.
         # VLATOUCH_DINO_PRECISION=bf16 restores bf16 storage.
+        # Range guard (round 6): fp16 storage is the DEFAULT of that mode, not a promise — the engine flags a saturated SwiGLU gate / a non-finite feature
+        # (DinoEngine.overflowed()), and unless VLATOUCH_DINO_PRECISION pins the type this encoder then rebuilds itself with bf16 storage and repeats the call.
         eng_prec = self.precision
+        self._range = None
         if eng_prec == "bf16":
-            eng_prec = os.environ.get("VLATOUCH_DINO_PRECISION", "fp16")
+            eng_prec = os.environ.get("VLATOUCH_DINO_PRECISION") or "fp16"
+            if "VLATOUCH_DINO_PRECISION" not in os.environ:
+                self._range = AutoRange(f"DINOv2Encoder({model_name})")
+        self._heads = cfg["heads"]
         self.engine = DinoEngine(sd, heads=cfg["heads"], precision=eng_prec, device=device)
         self.model = self          # the reference exposes `.model` (eval / to / parameters are no-ops on frozen weights)
 
@@ -143,7 +149,14 @@ class DINOv2Encoder:
             tens.append(t)
         if any(t.dtype != tens[0].dtype for t in tens):     # the engine reads every batch with ONE element type
             tens = [t.float() if t.dtype != torch.float32 else t for t in tens]
-        return self.engine.forward(tens, nhwc=nhwc, pre_scale=pre, norm_mode=norm_mode)
+        out = self.engine.forward(tens, nhwc=nhwc, pre_scale=pre, norm_mode=norm_mode)
+        if self._range is not None and not self._range.fell_back:
+            bits = self._range.after(self.engine, self.engine.adt == L.F16)
+            if bits:
+                self._range.fall_back(bits)
+                self.engine = DinoEngine(self._state_dict, heads=self._heads, precision="bf16", device=self.device)
+                out = self.engine.forward(tens, nhwc=nhwc, pre_scale=pre, norm_mode=norm_mode)
+        return out
 
     def forward(self, images):
         with torch.no_grad():

@@ -16,6 +16,15 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VLATOUCH_LIB: another build of the same library (tools/drain_waits_check.sh compares the product against a debug build); default = the in-tree product
 LIB_PATH = os.environ.get("VLATOUCH_LIB") or os.path.join(_HERE, "libvlatouch_hip.so")
 
+# bits of an engine's range-guard word (include/vlatouch.h, vt_rdt_set_range_flag / vt_dino_set_range_flag)
+RANGE_XN_SAT, RANGE_NONFINITE, RANGE_GATE_SAT, RANGE_ATTN_EMPTY = 1, 2, 4, 8
+RANGE_NAMES = {RANGE_XN_SAT: "xn_saturated", RANGE_NONFINITE: "nonfinite", RANGE_GATE_SAT: "gate_saturated", RANGE_ATTN_EMPTY: "attention_row_empty"}
+
+
+def range_names(bits: int):
+    return [n for b, n in RANGE_NAMES.items() if bits & b]
+
+
 F32, BF16, F32X3, F16 = 0, 1, 2, 3   # F32X3: fp32 storage, split-bf16 3-MFMA compute (GEMM weights only); F16: IEEE half
 ACT_NONE, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH, ACT_SWIGLU = 0, 1, 2, 3, 4, 5
 NORM_LAYER, NORM_RMS_MEANSQ, NORM_RMS_VAR = 0, 1, 2
@@ -48,6 +57,7 @@ class GemmParams(C.Structure):
         ("xn_out", C.c_void_p), ("xn_ld", C.c_long), ("xn_gain", C.c_void_p), ("xn_part", C.c_void_p),
         ("rs_part", C.c_void_p), ("rs_n", C.c_int), ("rs_inv_k", C.c_float), ("rs_eps", C.c_float), ("rs_mode", C.c_int),
         ("pf_ptr", C.c_void_p), ("pf_bytes", C.c_size_t),
+        ("range_flag", C.c_void_p),      # range-guard word (include/vlatouch.h, vt_rdt_set_range_flag); null = none
     ]
 
 
@@ -152,6 +162,7 @@ SIGNATURES = {
     "vt_dino_workspace_bytes": (_Z, [_P, _I, _I]),
     "vt_dino_packed_bytes": (_Z, [_P]),
     "vt_dino_set_packed": (_I, [_P, _P, _P]),
+    "vt_dino_set_range_flag": (_I, [_P, _P]),
     "vt_dino_forward": (_I, [_P, _P, _I, _I, _I, _F, _I, _I, _I, _P, _P, _P, _P, _P]),
     "vt_mlp": (_I, [_P, _L, _I, _I, _P, _P, _P, _I, _P, _I, _L, _I, _I, _P, _P]),
     "vt_concat_obs": (_I, [_P, _P, _I, _P, _I, _P, _I, _P, _I, _L, _I, _P]),
@@ -170,6 +181,7 @@ SIGNATURES = {
     "vt_rdt_set_io_dtype": (_I, [_P, _I]),
     "vt_rdt_packed_bytes": (_Z, [_P]),
     "vt_rdt_set_packed": (_I, [_P, _P, _P]),
+    "vt_rdt_set_range_flag": (_I, [_P, _P]),
     "vt_rdt_forward": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P, _P, _I, _I, _P, _P]),
     "vt_rdt_sample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _P, _I, _I, _P, _P]),
     "vt_im2col_t": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -51,6 +51,66 @@ class _Workspace:
         return buf
 
 
+class RangeGuard:
+    """Mixin of the engines with a 16-bit mode: ONE uint32 in device memory that the engine's kernels OR bits into when a value left the 16-bit type's range
+    (include/vlatouch.h, vt_rdt_set_range_flag / vt_dino_set_range_flag; bit names: vlatouch._lib.RANGE_NAMES).  Sticky across calls and hipGraph replays.
+      overflowed()        synchronises the device and returns the bits (0 = clean); `clear=True` re-zeroes the word
+      range_poll()        never blocks: returns the bits of the last asynchronous read-out that has completed and enqueues the next one on the current
+                          stream (a pinned 4-byte copy + an event; skipped while the stream is being captured into a hipGraph) — one call of lag"""
+
+    def _range_init(self, setter, what: str):
+        self._range = torch.zeros(1, dtype=torch.int32, device=self.device)
+        L.check(setter(self._h, L.ptr(self._range)), what)
+        self._range_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self._range_evt: Optional[torch.cuda.Event] = None
+        self._range_seen = 0
+
+    def overflowed(self, clear: bool = False) -> int:
+        torch.cuda.synchronize(self.device)
+        bits = int(self._range.item()) | self._range_seen
+        if clear:
+            self._range.zero_()
+            self._range_seen = 0
+            self._range_evt = None
+        return bits
+
+    def range_poll(self) -> int:
+        if torch.cuda.is_current_stream_capturing():
+            return self._range_seen
+        if self._range_evt is not None and self._range_evt.query():
+            self._range_seen |= int(self._range_host[0])
+            self._range_evt = None
+        if self._range_evt is None:
+            self._range_host.copy_(self._range, non_blocking=True)
+            self._range_evt = torch.cuda.Event()
+            self._range_evt.record(torch.cuda.current_stream(self.device))
+        return self._range_seen
+
+
+class AutoRange:
+    """Policy of the owners of a RangeGuard engine that runs a bf16 / fp32-trained model with IEEE fp16 storage BY DEFAULT (RDTRunner compute_dtype="auto",
+    the ViT encoders' low-precision mode): the first call is checked synchronously (weight-driven overflow shows on any input), later calls through the
+    engine's non-blocking read-out (one call of lag); nothing is read while a hipGraph is being captured.  `after()` returns the bits that ask for the
+    fallback to bf16 storage (0 = keep going); the owner rebuilds its engine and repeats the call."""
+
+    def __init__(self, what: str):
+        self.what, self.checked, self.fell_back, self.bits = what, False, False, 0
+
+    def after(self, eng: RangeGuard, is_f16: bool) -> int:
+        if not is_f16 or torch.cuda.is_current_stream_capturing():
+            return 0
+        if not self.checked:
+            self.checked = True
+            return eng.overflowed()
+        return eng.range_poll()
+
+    def fall_back(self, bits: int) -> None:
+        import warnings
+        self.fell_back, self.bits = True, bits
+        warnings.warn(f"{self.what}: activations left the IEEE fp16 range ({', '.join(L.range_names(bits))}); switching this model to bf16 storage "
+                      "(the reference's execution dtype) for this and all later calls", RuntimeWarning, stacklevel=4)
+
+
 # =========================================================================================== U-Net / SI sampler
 def _conv_tapmajor(w: torch.Tensor, cin_pad: int) -> torch.Tensor:
     """Conv1d weight [Cout, Cin, k] -> [Cout, k*cin_pad] with W'[co, tap*cin_pad + ci] = w[co, ci, tap]."""
@@ -224,7 +284,7 @@ class UNetEngine:
 
 
 # =========================================================================================== DINOv2
-class DinoEngine:
+class DinoEngine(RangeGuard):
     """HF Dinov2Model state dict -> CLS features (pooler_output)."""
 
     def __init__(self, sd: SD, *, heads: int, precision: str = "fp32", device="cuda", patch: int = 14, eps: float = 1e-6):
@@ -282,6 +342,7 @@ class DinoEngine:
             self._packed = torch.empty(nb, dtype=torch.uint8, device=self.device)
             L.check(lib.vt_dino_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(self.device)), "vt_dino_set_packed")
             torch.cuda.synchronize(self.device)
+        self._range_init(lib.vt_dino_set_range_flag, "vt_dino_set_range_flag")
         self._ws = _Workspace(self.device)
         self._pos_cache: Dict[int, torch.Tensor] = {}
         self.last_flags: Optional[torch.Tensor] = None
@@ -355,7 +416,7 @@ class DinoEngine:
 
 
 # =========================================================================================== SigLIP image tokens
-class SiglipEngine:
+class SiglipEngine(RangeGuard):
     """HF SiglipVisionModel state dict -> last_hidden_state [B, tokens, hidden] (the RDT image tower).
 
     Runs on the same ViT driver as DINOv2 (vt_dino_*): no CLS token, tanh-GELU, every token through the final LayerNorm.
@@ -436,6 +497,7 @@ class SiglipEngine:
         assert lib.vt_dino_num_weights(C.byref(desc)) == len(W)
         self._h = C.c_void_p()
         L.check(lib.vt_dino_create(C.byref(desc), L.ptr_array(W), len(W), C.byref(self._h)), "vt_dino_create (siglip)")
+        self._range_init(lib.vt_dino_set_range_flag, "vt_dino_set_range_flag")
         self._ws = _Workspace(self.device)
 
     def __del__(self):

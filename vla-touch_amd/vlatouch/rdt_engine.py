@@ -11,7 +11,7 @@ import torch
 
 from . import _lib as L
 from . import dpm
-from .engine import _Workspace
+from .engine import RangeGuard, _Workspace
 
 SD = Mapping[str, torch.Tensor]
 
@@ -25,7 +25,7 @@ def adaptor_depth(kind: str) -> int:
     return int(m.group(1))
 
 
-class RdtEngine:
+class RdtEngine(RangeGuard):
     def __init__(self, sd: SD, *, hidden: int, depth: int, heads: int, horizon: int, action_dim: int, lang_token_dim: int,
                  img_token_dim: int, state_token_dim: int, max_lang_cond_len: int, img_cond_len: int,
                  lang_adaptor: str = "mlp2x_gelu", img_adaptor: str = "mlp2x_gelu", state_adaptor: str = "mlp3x_gelu",
@@ -90,6 +90,10 @@ class RdtEngine:
         L.check(lib.vt_rdt_set_state_precision(self._h, int(solver_state == "fp32")), "vt_rdt_set_state_precision")
         if dtype != torch.float32 and self.io_dtype != torch.float32:
             L.check(lib.vt_rdt_set_io_dtype(self._h, L.dt_code(self.io_dtype)), "vt_rdt_set_io_dtype")
+        self._range_init(lib.vt_rdt_set_range_flag, "vt_rdt_set_range_flag")
+        # static side of the range guard: can the weights themselves be held in this 16-bit type?  (a bf16 checkpoint converted to IEEE fp16: |w| > 65504 became inf)
+        mats = [t for t in W if t.dtype == dtype and t.dtype != torch.float32]
+        self.weight_absmax = float(torch.stack([t.abs().max().float() for t in mats]).max()) if mats else 0.0
         self._ws = _Workspace(dev)
         # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
         self._depth, self._rms_mode = depth, rms_mode
@@ -101,15 +105,17 @@ class RdtEngine:
             L.check(lib.vt_rdt_set_packed(self._h, L.ptr(self._packed), L.stream_ptr(dev)), "vt_rdt_set_packed")
 
     def _set_score_bounds(self):
-        """|q . k| / 8 <= 8 max|w_q| max|w_k| for the mean-square per-head RMSNorm of cross_attn.q_norm / k_norm (blocks.py:86-87, 112-113)
-        (+2 %: the normed q / k are stored in bf16): lets the cached cross-attention drop its running maximum.  The variance form has no
-        such bound -> 0 (online softmax).  Weight order per block: see csrc/vt_rdt.hip (cq_norm at +12, ck_norm at +13)."""
+        """|q . k| / 8 <= 8 max_i |w_q[i] w_k[i]| for the mean-square per-head RMSNorm of cross_attn.q_norm / k_norm (blocks.py:86-87, 112-113):
+        q = q^ * w_q with |q^|_2 <= 8, likewise k, so |sum_i q^_i w_q[i] k^_i w_k[i]| <= max_i |w_q[i] w_k[i]| |q^| |k^| (round 6: the maximum of the PRODUCTS,
+        not the product of the maxima) (+2 %: the normed q / k are stored in 16 bits): lets the cached cross-attention drop its running maximum — for bounds
+        up to 40 with bf16 probabilities, up to 10 with IEEE fp16 ones (csrc/vt_attn_kvt.hip).  The variance form has no such bound -> 0 (online softmax).
+        Weight order per block: see csrc/vt_rdt.hip (cq_norm at +12, ck_norm at +13)."""
         bounds = (C.c_float * self._depth)()
         if self._rms_mode == "meansq" and self.dtype in (torch.bfloat16, torch.float16):
             for i in range(self._depth):
                 base = 11 + 21 * i
                 wq, wk = self._weights[base + 12], self._weights[base + 13]
-                bounds[i] = 8.0 * 1.02 * float(wq.abs().max()) * float(wk.abs().max())
+                bounds[i] = 8.0 * 1.02 * float((wq * wk).abs().max())
         self.score_bounds = [float(b) for b in bounds]      # 0 = unknown: that block's cross-attention keeps the online softmax
         L.check(L.lib().vt_rdt_set_score_bounds(self._h, bounds, self._depth), "vt_rdt_set_score_bounds")
 
@@ -171,6 +177,7 @@ class RdtEngine:
         L.check(L.lib().vt_rdt_forward(self._h, L.ptr(x), L.ptr(freq), L.ptr(tdev), float(t[0]) if scalar else 0.0, int(scalar), L.ptr(lang_c),
                                        L.ptr(img_c), L.ptr(mask), L.ptr(out), B, Llang, L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)),
                 "vt_rdt_forward")
+        self.range_poll()
         return out
 
     def sample(self, lang_tokens, lang_attn_mask, img_tokens, state_tokens, action_mask, ctrl_freqs, x_init, *, num_inference_steps: int,
@@ -214,4 +221,5 @@ class RdtEngine:
         L.check(L.lib().vt_rdt_sample(self._h, L.ptr(lang_tokens), L.ptr(mask), L.ptr(img_tokens), L.ptr(state_tokens), L.ptr(action_mask),
                                       L.ptr(ctrl_freqs), L.ptr(x_init), len(ts), ts_c, coef_c, int(prediction_type == "sample"), int(adapted), L.ptr(out), B, Llang,
                                       L.ptr(self._ws_for(B, Llang)), L.stream_ptr(dev)), "vt_rdt_sample")
+        self.range_poll()            # range guard: asynchronous read-out of the sticky word (no synchronisation; RangeGuard)
         return out if return_fp32 else out.to(self.io_dtype)
