@@ -324,6 +324,10 @@ int vt_gelu(const float* x, const float* dy, float* out, long n, vt_stream_t str
  * target_s = -z, target_b = (x1 - x0) + gamma'(t) z, t_clipped[B]; z already scaled by beta_max; gamma_type as vt_si_sample. */
 int vt_si_qsample(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s,
                   float* target_b, float* t_clipped, int B, long per_sample, int gamma_type, float t_min, vt_stream_t stream);
+/* the same for every `interpolant_type` of the reference (bridge_model.py:103-181: xt = w0(t) x0 + w1(t) x1 + gamma z, target_v = d(w0 x0 + w1 x1) / dt,
+ * target_b = target_v + gamma'(t) z): 0 linear, 1 power3, 2 power4, 3 reverse_power3, 4 reverse_power4, 5 gaussian_encode_decode, 6 reverse_linear */
+int vt_si_qsample_ex(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s,
+                     float* target_b, float* t_clipped, int B, long per_sample, int gamma_type, float t_min, int interpolant_type, vt_stream_t stream);
 /* loss[0] = mean_b(0.5 |out_b|^2 - <target_b, out_b>), dout = (out - target) / B   (the three interpolant losses share this form) */
 int vt_si_loss(const float* out, const float* target, float* dout, float* loss, int B, long per_sample, vt_stream_t stream);
 int vt_slab_sum(const float* slabs, int S, long n, const float* bias, int N, float* out, vt_stream_t stream);  /* split-K partials [S][n] -> out[n] (+ bias[i % N]) */

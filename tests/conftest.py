@@ -1,6 +1,11 @@
 import os
 import sys
 
+# the oracle legs of the GPU tests run torch CPU ops on 32 threads: OpenMP workers that sleep between parallel regions instead of spinning make them ~30 % faster on the
+# 128-core GPU boxes (bench.py's cpu_baseline sweep, round 6); must be set before torch loads its OpenMP runtime
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -192,20 +192,22 @@ def test_persistent_tile_fp32_residual_kind(dev, dtype, M, N, K, inplace):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("mode", ["meansq", "var"])
+@pytest.mark.parametrize("mode,shift", [("meansq", 2.0), ("var", 2.0), ("var", 400.0)])
 @pytest.mark.parametrize("M,N2,hn", [(2144, 6144, True), (2144, 2048, False), (2100, 2048, True)])
-def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn, mode):
+def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn, mode, shift):
     """The fused RMSNorm hand-off of the per-denoise-step Linears (vt_gemm.h xn_out / rs_part): residual Linear -> [norm] -> Linear with the norm launch
     replaced by (x * gain, (sum of squares, sum) per 64 columns) out of the first epilogue and a row scale in the second, against the three-launch form and
     torch fp32 — in both RmsNorm forms: mean-square (timm >= 1.0.9) and unbiased variance of the un-centred row (timm <= 1.0.8 incl. the timm==1.0.3
-    upstream RDT-1B pins, models/rdt/blocks.py:22,150-156).  The stream carries a row offset (mean ~ 0.6 of the rms) so that the two forms differ."""
+    upstream RDT-1B pins, models/rdt/blocks.py:22,150-156).  The stream carries a row offset (mean ~ 0.6 of the rms) so that the two forms differ; shift = 400
+    (round 6): |row mean| = 130 x the standard deviation, where sum x^2 - (sum x)^2 / K has lost 4 of fp32's 7 digits — the variance form hands over
+    centred second moments per 64 columns and merges them pairwise, as accurate as the two-pass row-norm kernel of the three-launch form."""
     from vlatouch import ops, _lib as L
     D = 2048
     m = L.NORM_RMS_MEANSQ if mode == "meansq" else L.NORM_RMS_VAR
     a = rnd((M, D), 1, dev, dtype)
     w1 = rnd((D, D), 2, dev, dtype, D ** -0.5)
     b1 = rnd((D,), 3, dev)
-    x0 = rnd((M, D), 4, dev) * 3.0 + 2.0
+    x0 = rnd((M, D), 4, dev) * 3.0 + shift
     gain = rnd((D,), 5, dev) * 0.2 + 1.0
     w2 = rnd((N2, D), 6, dev, dtype, D ** -0.5)
     b2 = rnd((N2,), 7, dev)
@@ -222,11 +224,12 @@ def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn, mode):
     xb = torch.cat([x0, torch.full((2, D), 7.0, device=dev)])                  # guard rows
     xo = torch.full((M + 2, D), 7.0, dtype=dtype, device=dev)
     part = torch.full((M + 2, 2 * D // 128, 2), 7.0, device=dev)
-    ops.gemm(a, w1, b1, residual=xb[:M], out=xb[:M], out_dtype=torch.float32, wp=wp1, xn=(xo[:M], gain, part[:M]))
+    ops.gemm(a, w1, b1, residual=xb[:M], out=xb[:M], out_dtype=torch.float32, wp=wp1, xn=(xo[:M], gain, part[:M], m))
     assert torch.equal(xb[:M], xa)                                             # the fp32 stream itself: the same arithmetic
     assert bool((xb[M:] == 7.0).all()) and bool((xo[M:] == 7.0).all()) and bool((part[M:] == 7.0).all())
-    sq = xa.double().pow(2).view(M, -1, 64).sum(-1)
-    sm = xa.double().view(M, -1, 64).sum(-1)
+    grp = xa.double().view(M, -1, 64)
+    sm = grp.sum(-1)
+    sq = grp.pow(2).sum(-1) if mode == "meansq" else (grp - grp.mean(-1, keepdim=True)).pow(2).sum(-1)      # variance form: about the 64 columns' own mean
     assert float((part[:M, :, 0].double() - sq).abs().max() / sq.max()) < 1e-5
     assert float((part[:M, :, 1].double() - sm).abs().max() / sm.abs().max()) < 1e-5
     y2 = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, m))
@@ -247,6 +250,8 @@ def test_rmsnorm_handoff_between_two_linears(dev, dtype, M, N2, hn, mode):
     y2b = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, m))
     assert torch.equal(y2, y2b)
     if mode == "var":      # and the two forms really differ on this stream (a consumer that ignored rs_mode would pass the mean-square reference)
-        y_ms = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part[:M].contiguous(), 1e-6, L.NORM_RMS_MEANSQ))
+        xc, part_ms = x0.clone(), torch.empty_like(part[:M])
+        ops.gemm(a, w1, b1, residual=xc, out=xc, out_dtype=torch.float32, wp=wp1, xn=(xo[:M], gain, part_ms, L.NORM_RMS_MEANSQ))
+        y_ms = ops.gemm(xo[:M], w2, b2, act=act, headnorm=head, wp=wp2, rs=(part_ms, 1e-6, L.NORM_RMS_MEANSQ))
         if not hn:
             assert float((y_ms.float() - y2.float()).abs().max()) / scale > 2e-2

@@ -120,6 +120,37 @@ def test_predict_action_vs_oracle_sampler(dname, dtype, compute):
             assert e32 <= 4e-3 * scale, (e32, scale)              # (the tiny config: D = 256 averages less than RDT-1B, where it is 7e-4 of the scale)
 
 
+def test_predict_action_reference_rounding_points_vs_bf16_golden():
+    """solver_state="bf16" + compute_dtype="bf16" reproduces the REFERENCE's own rounding points (the start noise drawn in bf16, `noisy_action.to(dtype)` after
+    every scheduler step, bf16 model output; models/rdt_runner.py:137-139,160): held to the oracle run in bf16 arithmetic (g9 ..._bf16, the reference-dtype golden)
+    so that the mode does not rot behind the fp32-state default.  Two bf16 executions of 4 blocks x 5 steps differ by rounding, not by bits: the bar is
+    their common distance to the fp32 result."""
+    g16 = G("g9_rdt_sample_bf16_UNPINNED")["out"]
+    exact = G("g9_rdt_sample_f32_UNPINNED")["out"]
+    cfg = cases.RDT_TINY
+    ri = cases.rdt_inputs(cfg, 2, 12, dtype=torch.bfloat16)
+    args = (ri["lang_tokens"], ri["lang_mask"], ri["img_tokens"], ri["state_tokens"], ri["action_mask"], ri["freq"])
+    from models.rdt_runner import RDTRunner
+    c = dict(RUNNER_CFG)
+    c["rdt"] = {"hidden_size": cfg["hidden"], "depth": cfg["depth"], "num_heads": cfg["heads"]}
+    outs = {}
+    for state in ("bf16", "fp32"):
+        r = RDTRunner(action_dim=cfg["action_dim"], pred_horizon=cfg["horizon"], config=c, lang_token_dim=cfg["lang_token_dim"], img_token_dim=cfg["img_token_dim"],
+                      state_token_dim=cfg["state_token_dim"], max_lang_cond_len=cfg["max_lang_cond_len"], img_cond_len=cfg["img_cond_len"], dtype=torch.bfloat16,
+                      device="cuda:0", compute_dtype="bf16", solver_state=state)
+        r.load_state_dict(cases.rdt_sd(cfg, torch.float32))
+        assert r.engine().solver_state == state
+        outs[state] = r.predict_action(*args, x_init=ri["x_init"], return_fp32=True)
+    scale = float(np.abs(exact).max())
+    o16 = outs["bf16"]
+    assert torch.equal(o16, o16.to(torch.bfloat16).float())                  # every value sits on the bf16 grid (the state is rounded after each step, the mask applied in bf16)
+    assert not torch.equal(outs["fp32"], outs["fp32"].to(torch.bfloat16).float())
+    e_mode, e_ref, e_pair = err(o16, exact), err(g16, exact), err(o16, g16)
+    print(f"[solver_state bf16] scale {scale:.2f}: |hip - exact| {e_mode:.3e}  |oracle16 - exact| {e_ref:.3e}  |hip - oracle16| {e_pair:.3e}  (fp32 state: {err(outs['fp32'], exact):.3e})")
+    assert e_mode <= max(1e-2 * scale, 1.5 * e_ref), (e_mode, e_ref)
+    assert e_pair <= e_mode + e_ref + 1e-6
+
+
 def test_conditional_sample_equals_predict_action_and_errors():
     from models.rdt_runner import RDTRunner
     cfg = cases.RDT_TINY

@@ -60,6 +60,40 @@ def test_training_step_matches_reference_autograd_adamw_ema():
         print(f"[train step {step}] loss {loss:.6f}; worst relative error: grads {wg:.2e}, params {wp:.2e}, ema {we:.2e}")
 
 
+INTERPOLANT_KINDS = ["power3", "power4", "reverse_power3", "reverse_power4", "gaussian_encode_decode", "reverse_linear"]
+
+
+@pytest.mark.parametrize("kind", INTERPOLANT_KINDS)
+def test_training_step_nonlinear_interpolants_match_reference_autograd(kind):
+    """Round 6: every `interpolant_type` of the reference (bridge_model.py:103-147 `interpolant`, :149-181 `interpolant_dev`) in the device
+    training step — q_sample + the three loss targets (vt_si_qsample_ex) -> losses, d loss / d obs_cond and all parameter gradients against ONE get_loss +
+    backward of the reference itself per interpolant (tools/make_golden_train.py --interpolants -> g13_train_interpolants.npz), each paired with one of the three
+    gamma schedules; t includes both clipped ends and both sides of the piecewise interpolants' indicator (0.5, 0.5 + 1 ulp)."""
+    from vlatouch.train import SITrainer
+    g = np.load(f"{cases.GOLDEN}/g13_train_interpolants.npz")
+    names = [str(n) for n in g["names"]]
+    gamma = str(g[f"{kind}_gamma"])
+    tr = SITrainer(cases.si_net_sd(""), cases.state_encoder_sd(781), gamma_type=gamma, interpolant_type=kind, lr=1e-4, weight_decay=1e-6, device="cuda:0")
+    inp = train_inputs(1)
+    inp["t"] = cases.T(g["t"])
+    loss, info = tr.get_loss(inp["obs_in"], inp["vla_n"], inp["expert_n"], inp["t"], inp["z"])
+    want = g[f"{kind}_loss"]
+    got = np.array([loss, info["v_loss"], info["s_loss"], info["b_loss"]])
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max(), (kind, got, want)
+    e = float(np.abs(tr.last_dcond.cpu().numpy() - g[f"{kind}_dcond"]).max())
+    assert e < 1e-4 * float(np.abs(g[f"{kind}_dcond"]).max()), (kind, e)
+    grads = dict(tr.net_grads())
+    grads.update({"state_encoder." + k: v for k, v in tr.mlp.grads().items()})
+    wg = check(g[f"{kind}_grad"], names, grads, "grad", 1e-4)
+    print(f"[train {kind} / {gamma}] loss {loss:.6f}; worst relative gradient error {wg:.2e}")
+
+
+def test_training_step_rejects_unknown_interpolant():
+    from vlatouch.train import SITrainer
+    with pytest.raises(NotImplementedError):
+        SITrainer(cases.si_net_sd(""), None, interpolant_type="cubic", device="cuda:0")
+
+
 def test_training_primitives_against_torch_cpu():
     """The data-movement pieces (transposed im2col, flipped weights, zero stuffing, column sums) and the activation derivatives."""
     from vlatouch import train as tt

@@ -113,8 +113,54 @@ def time_reference(batch: int = 128, iters: int = 3):
           f"= {batch / min(ts[1:]):.0f} samples/s")
 
 
+# every non-linear `interpolant_type` the reference accepts (bridge_model.py:103-181), each with one of its gamma schedules
+INTERPOLANTS = [("power3", "2^0.5*t(t-1)"), ("power4", "(2t(t-1))^0.5"), ("reverse_power3", "(1-t)^2(2t)^0.5"), ("reverse_power4", "2^0.5*t(t-1)"),
+                ("gaussian_encode_decode", "(2t(t-1))^0.5"), ("reverse_linear", "2^0.5*t(t-1)")]
+
+
+def interpolants():
+    """One get_loss + backward of the REFERENCE per non-linear interpolant (round 6): losses, d loss / d obs_cond and the per-tensor gradient
+    summaries -> tests/golden/g13_train_interpolants.npz (keys `<interpolant>_loss|dcond|grad`, `names`, `<interpolant>_gamma`)."""
+    ref_import.setup()
+    ref_import.no_cuda()
+    from bridge.bridge_model import StochasticInterpolants  # reference
+    out = {}
+    orig_rand, orig_randn_like = torch.rand, torch.randn_like
+    inp = train_inputs(1)
+    inp["t"][2], inp["t"][3] = 0.5, 0.5000001                              # both sides of the indicator of the piecewise interpolants
+    for kind, gamma in INTERPOLANTS:
+        args = dict(cases.MODEL_ARGS, interpolant_type=kind, gamma_type=gamma)
+        si = StochasticInterpolants()
+        si.load_model(args, "cpu")
+        si.net.load_state_dict(cases.si_net_sd(""))
+        si.net.train()
+        enc = torch.nn.Sequential(torch.nn.Linear(781, 256), torch.nn.GELU(), torch.nn.Linear(256, 256), torch.nn.GELU(), torch.nn.Linear(256, 256))
+        enc.load_state_dict(cases.state_encoder_sd(781))
+        torch.rand = lambda *a, **k: inp["t"].clone()
+        torch.randn_like = lambda x, *a, **k: inp["z"].clone()
+        try:
+            cond = enc(inp["obs_in"])
+            cond.retain_grad()
+            loss, info = si.get_loss({"obs_cond": cond, "expert_act": inp["expert_n"], "vla_act": inp["vla_n"]}, "cpu")
+            loss.backward()
+        finally:
+            torch.rand, torch.randn_like = orig_rand, orig_randn_like
+        named = list(si.net.named_parameters()) + [("state_encoder." + k, p) for k, p in enc.named_parameters()]
+        out["names"] = np.array([k for k, _ in named])
+        out[f"{kind}_gamma"] = np.array(gamma)
+        out[f"{kind}_loss"] = np.array([float(loss), float(info["v_loss"]), float(info["s_loss"]), float(info["b_loss"])])
+        out[f"{kind}_dcond"] = cond.grad.numpy().copy()
+        out[f"{kind}_grad"] = np.stack([summary(k, p.grad) for k, p in named])
+        print(kind, gamma, out[f"{kind}_loss"])
+    out["t"] = inp["t"].numpy()
+    np.savez_compressed(os.path.join(cases.GOLDEN, "g13_train_interpolants.npz"), **out)
+    print("wrote g13_train_interpolants", len(out), "arrays")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "--time":
+    if len(sys.argv) > 1 and sys.argv[1] == "--interpolants":
+        interpolants()
+    elif len(sys.argv) > 1 and sys.argv[1] == "--time":
         time_reference(int(sys.argv[2]) if len(sys.argv) > 2 else 128)
     else:
         main()

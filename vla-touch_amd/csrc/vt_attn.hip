@@ -1020,7 +1020,8 @@ int vt_attn_launch(const VtAttnParams& p, hipStream_t s) {
   // vt_tune(9, v) / VLATOUCH_ATTN16G: 0 = never, 1 = that policy (default), 3 / 6 = every 16-bit unmasked call with G pinned (tests, A/B).
   if (g_vt_attn16g < 0) { const char* e = getenv("VLATOUCH_ATTN16G"); g_vt_attn16g = e ? atoi(e) : 1; }
   const int a16g = g_vt_attn16g;
-  if (a16 && a16g && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nq >= 128 && (p.hd == 0 || p.hd == 64 || p.hd == 80)) {
+  // (only under the default variant selection: VLATOUCH_ATTN16=1, the A/B switch for the rolled attn16_kernel, must reach the kernel it names — ADVICE r5)
+  if (a16 == 2 && a16g && p.dtype != VT_F32 && !p.kmask && p.o_rs % 4 == 0 && p.Nq >= 128 && (p.hd == 0 || p.hd == 64 || p.hd == 80)) {
     const int need = (p.Nq + 15) / 16;
     int bG = 0, bW = 0;
     if (a16g == 3 || a16g == 6) {                     // pinned: fewest blocks per (image, head), then fewest groups in them, then more waves

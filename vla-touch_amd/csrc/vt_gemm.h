@@ -45,7 +45,8 @@ struct VtGemmParams {
   //   consumer (A = that xn_out): every accumulator row is multiplied by rstd[m] before the bias — (x * gain) W^T * rstd = (x * rstd * gain) W^T, the
   //     norm launch between the two Linears disappears.  With Q = sum_{j < rs_n} rs_part[m][j][0], S = sum_j rs_part[m][j][1], K = 1 / rs_inv_k:
   //       rs_mode 0 / 1 (mean-square, timm >= 1.0.9):            rstd = rsqrt(Q / K + rs_eps)
-  //       rs_mode 2 (unbiased variance, x not centred, <= 1.0.8): rstd = rsqrt((Q - S^2 / K) / (K - 1) + rs_eps)
+  //       rs_mode 2 (unbiased variance, x not centred, <= 1.0.8): rstd = rsqrt(M2 / (K - 1) + rs_eps); for this form the PRODUCER (which is given rs_mode too) writes
+  //         xn_part[m][j] = (second moment of the 64 columns about their own mean, sum) and the consumer merges the groups pairwise (Chan et al.) — never Q - S^2 / K
   void* xn_out; long xn_ld; const float* xn_gain; float* xn_part;
   const float* rs_part; int rs_n; float rs_inv_k, rs_eps; int rs_mode;
   // prefetch hint (vt_gemm_pw.hip): pf_bytes of memory at pf_ptr — the NEXT launch's frozen weights — are touched (one dword per 64 bytes, dealt over the

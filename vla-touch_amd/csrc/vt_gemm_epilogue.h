@@ -22,7 +22,9 @@ __device__ __forceinline__ void vt_epi_st128(void* ptr, const float4 v) {
 #elif VT_EPI_ST_POLICY == 2
   typedef __attribute__((ext_vector_type(4))) float f4v;
   const f4v t = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(ptr), "v"(t) : "memory");
+  // s_nop: a > 8-byte store reads its data registers a few cycles after issue; hipcc inserts that wait state behind its own stores but does not look inside inline
+  // asm (tools/ubench/band_seam.hip, round 6: without it the next VALU write corrupted 20 % of the stored words)
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 2" ::"v"(ptr), "v"(t) : "memory");
 #else
   *reinterpret_cast<float4*>(ptr) = v;
 #endif

@@ -234,14 +234,31 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
 #pragma unroll
     for (int i = 0; i < RSV; ++i) {
       const int q = tid + 256 * i;
-      if (q < BM * h2) pair[q] = make_float2(rsv[i].x + rsv[i].z, rsv[i].y + rsv[i].w);
+      if (q < BM * h2) {
+        // mean-square form: (sum x^2, sum x) of two 64-column groups add; variance form: (M2, sum) of two groups of 64 merge as M2a + M2b + (Sa - Sb)^2 / 128
+        const float dS = rsv[i].y - rsv[i].w;
+        pair[q] = make_float2(rsv[i].x + rsv[i].z + (p.rs_mode == 2 ? dS * dS * (1.0f / 128.0f) : 0.f), rsv[i].y + rsv[i].w);
+      }
     }
     __syncthreads();
     if (tid < BM) {
-      float sq = 0.f, sm = 0.f;
-      for (int c = 0; c < h2; ++c) { const float2 v = pair[tid * h2 + c]; sq += v.x; sm += v.y; }
-      float var = sq * p.rs_inv_k;
-      if (p.rs_mode == 2) { const float kf = 1.0f / p.rs_inv_k; var = fmaxf(sq - sm * sm * p.rs_inv_k, 0.f) / (kf - 1.0f); }
+      float var;
+      if (p.rs_mode == 2) {
+        // merge the h2 groups of 128 columns in a fixed order: M2 += M2_b + delta^2 n_a n_b / (n_a + n_b), delta = mean_b - mean_a
+        float na = 0.f, mean = 0.f, m2 = 0.f;
+        for (int c = 0; c < h2; ++c) {
+          const float2 v = pair[tid * h2 + c];
+          const float delta = v.y * (1.0f / 128.0f) - mean, nt = na + 128.0f;
+          mean += delta * (128.0f / nt);
+          m2 += v.x + delta * delta * (na * 128.0f / nt);
+          na = nt;
+        }
+        var = m2 / (1.0f / p.rs_inv_k - 1.0f);
+      } else {
+        float sq = 0.f;
+        for (int c = 0; c < h2; ++c) sq += pair[tid * h2 + c].x;
+        var = sq * p.rs_inv_k;
+      }
       tile[tid] = rsqrtf(var + p.rs_eps);
     }
     __syncthreads();
@@ -334,8 +351,15 @@ __global__ __launch_bounds__(256, 1) void gemm_pw_kernel(const VtGemmParams p, c
         o[0] *= cs4.x; o[1] *= cs4.y; o[2] *= cs4.z; o[3] *= cs4.w;
         o[0] += rpre[it].x; o[1] += rpre[it].y; o[2] += rpre[it].z; o[3] += rpre[it].w;
         const bool ok = m < p.M && col_ok;
-        const float q = row16_sum(ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f);
         const float q1 = row16_sum(ok ? (o[0] + o[1]) + (o[2] + o[3]) : 0.f);           // the variance form of the consumer also needs the row sum
+        float q;
+        if (p.rs_mode == 2) {
+          // variance form (round 6): the second moment of the 64 columns about THEIR OWN mean — the consumer merges the groups pairwise (Chan et al.), so the
+          // row variance never comes from sum x^2 - (sum x)^2 / K, which cancels when |row mean| >> std (the un-fused row-norm kernels centre in two passes too)
+          const float mj = q1 * (1.0f / 64.0f);
+          const float d0 = o[0] - mj, d1 = o[1] - mj, d2 = o[2] - mj, d3 = o[3] - mj;
+          q = row16_sum(ok ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f);
+        } else q = row16_sum(ok ? (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]) : 0.f);
         if (ok) {
           vt_epi_st128(reinterpret_cast<float*>(Cg) + (long)m * p.ldc + n, make_float4(o[0], o[1], o[2], o[3]));
           // x * gain is NOT normalised yet (the consumer applies rstd): in IEEE fp16 a residual-stream outlier could leave the range — saturate instead of inf

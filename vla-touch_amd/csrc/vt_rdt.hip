@@ -287,6 +287,7 @@ int rgemm(RCtx& c, VtGemmParams p, const char* what, const float* hn_w0 = nullpt
     if (c.fuse_norm && pw_fuse && next_norm && xn_done && p.residual == p.C && p.c_dtype == VT_F32 && p.N == c.h->d.hidden && p.act == VT_ACT_NONE && p.ldc == p.N) {
       VtGemmParams q = p;
       q.xn_out = c.ws + c.w.xn; q.xn_ld = p.N; q.xn_gain = next_norm; q.xn_part = (float*)(c.ws + c.w.rs_part);
+      q.rs_mode = c.h->d.rms_mode;      // the variance form hands over centred second moments (vt_gemm.h)
       if (vt_gemm_fast_eligible(q) && vt_gemm_pw_eligible(q)) {
         p = q;
         *xn_done = true;

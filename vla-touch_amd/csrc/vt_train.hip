@@ -213,9 +213,17 @@ __global__ void gelu_kernel(const float* __restrict__ x, const float* __restrict
 //   tc = clip(t_b, t_min, 1 - t_min);  xt = (1 - tc) x0 + tc x1 + gamma(tc) z
 //   target_v = x1 - x0;  target_s = -z;  target_b = (x1 - x0) + gamma'(tc) z;   tclip[b] = tc
 // gamma_type: 0 = 1.4142 t (1 - t), 1 = 1.4142 sqrt(t (1 - t)), 2 = 1.4142 (1 - t)^2 sqrt(t)   (the constants the reference writes)
+// interp (round 6; bridge_model.py:103-147 `interpolant`, :149-181 `interpolant_dev`): xt = w0 x0 + w1 x1 + gamma z, target_v = d(w0 x0 + w1 x1) / dt
+//   0 linear                 w0 = 1 - t            w1 = t                 dv = x1 - x0
+//   1 power3                 w0 = (1 - t)^3        w1 = 1 - w0            dv = 3 (1 - t)^2 (x1 - x0)
+//   2 power4                 w0 = (1 - t)^4        w1 = 1 - w0            dv = 4 (1 - t)^3 (x1 - x0)
+//   3 reverse_power3         w0 = 1 - t^3          w1 = t^3               dv = 3 t^2 (x1 - x0)
+//   4 reverse_power4         w0 = 1 - t^4          w1 = t^4               dv = 4 t^3 (x1 - x0)
+//   5 gaussian_encode_decode w0 = cos^2(pi t) [t <= .5], w1 = cos^2(pi t) [t > .5]     dv = -2 pi cos(pi t) sin(pi t) ([t <= .5] x0 + [t > .5] x1)
+//   6 reverse_linear         w0 = (1 - 2t) [t <= .5],  w1 = 1 - w0        dv = 2 [t <= .5] (x1 - x0)
 __global__ void si_qsample_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ z, const float* __restrict__ t,
                                   float* __restrict__ xt, float* __restrict__ tv, float* __restrict__ ts, float* __restrict__ tb, float* __restrict__ tclip,
-                                  int B, long per, int gamma_type, float t_min) {
+                                  int B, long per, int gamma_type, float t_min, int interp) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= (long)B * per) return;
   const int b = (int)(i / per);
@@ -226,10 +234,25 @@ __global__ void si_qsample_kernel(const float* __restrict__ x0, const float* __r
                               gd = 1.4142f * (2.0f * (tc - 1.0f) * sqrtf(tc) + (1.0f - tc) * (1.0f - tc) / (2.0f * sqrtf(tc + 1e-4f))); }
   else { g = 1.4142f * tc * (1.0f - tc); gd = 1.4142f * (1.0f - 2.0f * tc); }
   const float a = x0[i], c = x1[i], zz = z[i];
-  xt[i] = (1.0f - tc) * a + tc * c + g * zz;
-  tv[i] = c - a;
+  float w0 = 1.0f - tc, w1 = tc, dv = c - a;
+  if (interp != 0) {
+    const float u = 1.0f - tc, lo = tc <= 0.5f ? 1.0f : 0.0f;
+    switch (interp) {
+      case 1: w0 = u * u * u; w1 = 1.0f - w0; dv = 3.0f * (u * u) * (c - a); break;
+      case 2: w0 = powf(u, 4.0f); w1 = 1.0f - w0; dv = 4.0f * (u * u * u) * (c - a); break;
+      case 3: w1 = tc * tc * tc; w0 = 1.0f - w1; dv = 3.0f * (tc * tc) * (c - a); break;
+      case 4: w1 = powf(tc, 4.0f); w0 = 1.0f - w1; dv = 4.0f * (tc * tc * tc) * (c - a); break;
+      case 5: { const float cs = cosf(tc * 3.14159265358979323846f), sn = sinf(3.14159265358979323846f * tc), c2 = cs * cs;
+                w0 = c2 * lo; w1 = c2 * (1.0f - lo);
+                const float k = -2.0f * 3.14159265358979323846f * cs * sn;
+                dv = k * lo * a + k * (1.0f - lo) * c; break; }
+      default: w0 = (1.0f - 2.0f * tc) * lo; w1 = 1.0f - w0; dv = -2.0f * lo * a + 2.0f * lo * c; break;
+    }
+  }
+  xt[i] = w0 * a + w1 * c + g * zz;
+  tv[i] = dv;
   ts[i] = -zz;
-  tb[i] = (c - a) + gd * zz;
+  tb[i] = dv + gd * zz;
   if (i % per == 0) tclip[b] = tc;
 }
 
@@ -396,13 +419,18 @@ int vt_gelu(const float* x, const float* dy, float* out, long n, vt_stream_t s) 
   hipLaunchKernelGGL(gelu_kernel, g1(n), dim3(256), 0, (hipStream_t)s, x, dy, out, n);
   return LAUNCH_OK();
 }
-int vt_si_qsample(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s, float* target_b,
-                  float* t_clipped, int B, long per_sample, int gamma_type, float t_min, vt_stream_t s) {
-  if (!x0 || !x1 || !z || !t || !xt || !target_v || !target_s || !target_b || !t_clipped || B < 1 || per_sample < 1 || gamma_type < 0 || gamma_type > 2)
+int vt_si_qsample_ex(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s, float* target_b,
+                     float* t_clipped, int B, long per_sample, int gamma_type, float t_min, int interpolant_type, vt_stream_t s) {
+  if (!x0 || !x1 || !z || !t || !xt || !target_v || !target_s || !target_b || !t_clipped || B < 1 || per_sample < 1 || gamma_type < 0 || gamma_type > 2 ||
+      interpolant_type < 0 || interpolant_type > 6)
     return vt_fail(VT_ERR_ARG, "vt_si_qsample: bad argument");
   hipLaunchKernelGGL(si_qsample_kernel, g1((long)B * per_sample), dim3(256), 0, (hipStream_t)s, x0, x1, z, t, xt, target_v, target_s, target_b, t_clipped, B,
-                     per_sample, gamma_type, t_min);
+                     per_sample, gamma_type, t_min, interpolant_type);
   return LAUNCH_OK();
+}
+int vt_si_qsample(const float* x0, const float* x1, const float* z, const float* t, float* xt, float* target_v, float* target_s, float* target_b,
+                  float* t_clipped, int B, long per_sample, int gamma_type, float t_min, vt_stream_t s) {
+  return vt_si_qsample_ex(x0, x1, z, t, xt, target_v, target_s, target_b, t_clipped, B, per_sample, gamma_type, t_min, 0, s);
 }
 int vt_si_loss(const float* out, const float* target, float* dout, float* loss, int B, long per_sample, vt_stream_t s) {
   if (!out || !target || !dout || !loss || B < 1 || per_sample < 1) return vt_fail(VT_ERR_ARG, "vt_si_loss: bad argument");

@@ -31,10 +31,10 @@ _TINY = 1e-4       # its guard against 1/0 at the interval ends
 # epsilon_type -> eps(t)
 _EPSILON_OF_T = {
     "1-t": lambda t, si: 1.0 - t,
-    "t(t-1)": lambda t, si: t - t * t,
+    "t(t-1)": lambda t, si: t * (1 - t),
     "1-sqrt(t)": lambda t, si: 1.0 - t.sqrt(),
     "1-t^2": lambda t, si: 1.0 - t * t,
-    "0": lambda t, si: torch.zeros_like(t),
+    "0": lambda t, si: t * 0.0,
 }
 # gamma_type -> (gamma(t), d gamma / dt, the guarded denominator whose reciprocal — clamped to [0, gamma_inv_max] — is gamma_inv(t))
 _GAMMA_OF_T = {
@@ -79,7 +79,7 @@ class StochasticInterpolants:
             f = table[key]
         except KeyError:
             raise NotImplementedError(key) from None
-        return f(torch.as_tensor(t) if not torch.is_tensor(t) else t, self)
+        return f(t, self)      # `t` as the caller gave it: a Python float stays a float where the formula has no torch call, exactly as in the reference
 
     def epsilon(self, t):
         return self._schedule(_EPSILON_OF_T, self.epsilon_type, t)

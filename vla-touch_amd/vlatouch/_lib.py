@@ -195,6 +195,7 @@ SIGNATURES = {
     "vt_gn_mish_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "vt_gelu": (_I, [_P, _P, _P, _L, _P]),
     "vt_si_qsample": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _P]),
+    "vt_si_qsample_ex": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _L, _I, _F, _I, _P]),
     "vt_si_loss": (_I, [_P, _P, _P, _P, _I, _L, _P]),
     "vt_slab_sum": (_I, [_P, _I, _L, _P, _I, _P, _P]),
     "vt_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),

@@ -23,7 +23,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     headnorm = (w0[64], c0_end, w1[64] | None, c1_end, eps, mode): fused per-head RMSNorm (large bf16 GEMMs only).
     cmap = (mode, T) with out= a [H, T, 2, 64, 64] tile stream (T = ceil(M/64)): the cached-condition K (mode 1) / Vt (mode 2) layout.
     RMSNorm hand-off between two Linears on the weights-in-registers tile (csrc/vt_gemm.h): xn = (xn_out [M, N] 16-bit, gain [N] fp32, part [M, 2N/128, 2] fp32:
-    (sum of squares, sum) per 64 columns) on the residual Linear (fp32 out), rs = (part, eps[, mode = NORM_RMS_MEANSQ | NORM_RMS_VAR]) on the Linear that reads
+    (sum of squares, sum) per 64 columns — with mode = NORM_RMS_VAR as a 4th entry: (second moment about the 64 columns' own mean, sum)) on the residual Linear (fp32 out), rs = (part, eps[, mode = NORM_RMS_MEANSQ | NORM_RMS_VAR]) on the Linear that reads
     xn_out as `a`."""
     assert a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
     M, K = a.shape
@@ -57,7 +57,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert sk_cnt.dtype == torch.int32
         p.sk_ws, p.sk_ws_bytes, p.sk_cnt, p.sk_cnt_n = sk_ws.data_ptr(), sk_ws.numel() * sk_ws.element_size(), sk_cnt.data_ptr(), sk_cnt.numel()
     if xn is not None:
-        xo, gain, part = xn
+        xo, gain, part = xn[:3]
+        p.rs_mode = xn[3] if len(xn) > 3 else L.NORM_RMS_MEANSQ      # the variance form hands over CENTRED second moments per 64 columns (csrc/vt_gemm.h)
         assert xo.shape == (M, N) and xo.dtype == a.dtype and gain.dtype == torch.float32 and part.dtype == torch.float32 and part.shape == (M, 2 * N // 128, 2) and part.is_contiguous()
         p.xn_out, p.xn_ld, p.xn_gain, p.xn_part = xo.data_ptr(), xo.stride(0), gain.data_ptr(), part.data_ptr()
     if rs is not None:

@@ -496,6 +496,8 @@ class TrainMLP:
 
 # ---------------------------------------------------------------------------------------------- the training step
 _GAMMA = {"2^0.5*t(t-1)": 0, "(2t(t-1))^0.5": 1, "(1-t)^2(2t)^0.5": 2}
+# interpolant_type -> code of vt_si_qsample_ex (every string bridge_model.py:103-147 accepts)
+_INTERPOLANT = {"linear": 0, "power3": 1, "power4": 2, "reverse_power3": 3, "reverse_power4": 4, "gaussian_encode_decode": 5, "reverse_linear": 6}
 
 
 class _Optimizer:
@@ -590,8 +592,9 @@ class SITrainer(_Optimizer):
 
     def __init__(self, net_sd, mlp_sd=None, *, gamma_type="2^0.5*t(t-1)", interpolant_type="linear", beta_max=0.03, lr=1e-4, weight_decay=1e-6,
                  betas=(0.9, 0.999), eps=1e-8, ema_decay=0.75, device="cuda"):
-        if interpolant_type != "linear":
-            raise NotImplementedError("only the 'linear' interpolant is trained on the device")
+        if interpolant_type not in _INTERPOLANT:                   # the reference raises NotImplementedError for an unknown string too (bridge_model.py:145)
+            raise NotImplementedError(interpolant_type)
+        self.interpolant_type = _INTERPOLANT[interpolant_type]
         if gamma_type not in _GAMMA:
             raise NotImplementedError(gamma_type)
         self.device = L.require_gpu(device)
@@ -632,8 +635,8 @@ class SITrainer(_Optimizer):
         cond = self.mlp.forward(obs) if self.mlp is not None else obs
         xt, tv, ts, tb = (torch.empty_like(x0) for _ in range(4))
         tc = _empty((B,), dev)
-        L.check(L.lib().vt_si_qsample(L.ptr(x0), L.ptr(x1), L.ptr(z), L.ptr(t), L.ptr(xt), L.ptr(tv), L.ptr(ts), L.ptr(tb), L.ptr(tc), B, T * D,
-                                      self.gamma_type, self.t_min, _sp(dev)), "vt_si_qsample")
+        L.check(L.lib().vt_si_qsample_ex(L.ptr(x0), L.ptr(x1), L.ptr(z), L.ptr(t), L.ptr(xt), L.ptr(tv), L.ptr(ts), L.ptr(tb), L.ptr(tc), B, T * D,
+                                         self.gamma_type, self.t_min, self.interpolant_type, _sp(dev)), "vt_si_qsample_ex")
         losses, dcond = {}, None
         for name, tgt in (("v_net", tv), ("s_net", ts), ("b_net", tb)):
             out = self.nets[name].forward(xt, tc, cond)
