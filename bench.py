@@ -534,6 +534,10 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
     except Exception:
         pass
+    # the counters are a BUILDER-side measurement (separate rocprofv3 --pmc passes, tools/profile_round.sh) read from a committed file, not taken in this run:
+    # stamped with the fingerprint of the kernel sources they were taken on and whether that is the tree this bench runs from
+    traffic_source = {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False, "csrc_sha16_of_counters": pmc.get("csrc_sha16"),
+                      "csrc_sha16_of_this_tree": L.csrc_sha16(), "same_kernel_sources": pmc.get("csrc_sha16") == L.csrc_sha16()} if pmc else None
 
     def roof(mode, name, pmc_key):
         ms_, fl_, by_, n_ = prof[mode]
@@ -546,6 +550,7 @@ def main():
                 "share_of_step_time": round(ms_ / (1000 * elapsed / args.steps), 3),
                 "traffic": (round(pmc[pmc_key]["per_launch_bytes"] / 1e9, 4) if pmc_key in pmc else None),
                 "traffic_unit": "GB per launch (PMC 2*FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json)",
+                "traffic_source": traffic_source,
                 "algorithmic_gbytes_per_launch": round(by_ / 1e9 / n_, 4)}
     # on-box measured peaks (report fractions of the nominal AND of a measured peak): a large square bf16 GEMM on the
     # same kernel family and a device-to-device copy (read + write bytes)

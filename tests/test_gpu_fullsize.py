@@ -62,7 +62,7 @@ def test_rdt_1b_batch_invariance_determinism_and_mask(rdt1b):
         alone = run(rdt1b, d, slice(b, b + 1))
         e = float((alone[0] - full[b]).abs().max())
         print(f"[RDT-1B batch invariance row {b}] {e:.3e} (scale {scale:.2f})")
-        assert e <= 1e-2 * scale, (b, e, scale)
+        assert e <= 1e-2, (b, e, scale)                # FLAT (round 6): the north star's 1e-2 itself, not 1e-2 of the scale
     # language tokens under a False mask do not matter
     d2 = dict(d)
     d2["mask"] = d["mask"].clone()
@@ -216,7 +216,7 @@ def _oracle_episode_uncached(r, d, b, steps):
 def test_rdt_1b_batch32_rows_vs_oracle(rdt1b):
     """BASELINE configs[3]'s RDT leg exactly as bench.py times it: B=32 (M = 2144 rows / 139 968 condition rows -> gemm_ppk_kernel,
     gemm_pp256_kernel<..,1|2> and the un-split attn_kvt_kernel), 5 DPM-Solver++ steps; rows 0 and 31 against the oracle run on those
-    single episodes.  Bar: 1e-2 of the output scale (bf16 storage, 28 blocks x 5 steps; models/rdt_runner.py:122-165,225-250)."""
+    single episodes.  Bar: the north star's FLAT 1e-2 on the chunk (round 6; the product default = fp16 activations under the range guard; models/rdt_runner.py:122-165,225-250)."""
     d = rdt_inputs(32, seed=17)
     rdt1b.num_inference_timesteps = 5
     full = run(rdt1b, d)
@@ -226,7 +226,7 @@ def test_rdt_1b_batch32_rows_vs_oracle(rdt1b):
         scale = float(ref.abs().max())
         e = float((full[b].cpu() - ref).abs().max())
         print(f"[RDT-1B B=32 row {b}] scale {scale:.3f}  |hip16 - oracle32| {e:.3e}  ({e / scale:.2e} of scale)")
-        assert e <= 1e-2 * max(1.0, scale), (b, e, scale)
+        assert e <= 1e-2, (b, e, scale)                # FLAT 1e-2 (round 6; measured 4.3e-3 in the returned bf16, 8e-4 on the fp32 hand-over)
 
 
 def test_rdt_1b_batch32_activation_types_and_rmsnorm_forms_vs_oracle():
@@ -256,8 +256,8 @@ def test_rdt_1b_batch32_activation_types_and_rmsnorm_forms_vs_oracle():
         torch.cuda.empty_cache()
     print("[RDT-1B B=32 row 0] |hip - oracle32|: " + ", ".join(f"{c} activations / {m}: {e:.3e} (scale {scales[m]:.2f})" for (c, m), e in errs.items()))
     s_ms, s_var = max(1.0, scales["meansq"]), max(1.0, scales["var"])
-    assert errs[("bf16", "meansq")] <= 1e-2 * s_ms and errs[("f16", "meansq")] <= 2.5e-3 * s_ms and 3 * errs[("f16", "meansq")] <= errs[("bf16", "meansq")], errs
-    assert errs[("f16", "var")] <= 2.5e-3 * s_var, errs
+    assert errs[("bf16", "meansq")] <= 1e-2 * s_ms and errs[("f16", "meansq")] <= 2.5e-3 and 3 * errs[("f16", "meansq")] <= errs[("bf16", "meansq")], errs      # fp16: flat
+    assert errs[("f16", "var")] <= 2.5e-3, errs
 
 
 @pytest.mark.slow
@@ -273,12 +273,12 @@ def test_rdt_1b_50_steps_batch16(rdt1b):
         alone = run(rdt1b, d, slice(5, 6))
         e_inv = float((alone[0] - full[5]).abs().max())
         print(f"[RDT-1B 50 steps] scale {scale:.3f}  batch-invariance row 5: {e_inv:.3e}")
-        assert e_inv <= 1e-2 * scale, (e_inv, scale)
+        assert e_inv <= 1e-2, (e_inv, scale)
         ref = _oracle_episode(rdt1b, d, 0, 50)
         e = float((full[0].cpu() - ref).abs().max())
         rs = float(ref.abs().max())
         print(f"[RDT-1B B=16 50 steps row 0] scale {rs:.3f}  |hip16 - oracle32| {e:.3e}  ({e / rs:.2e} of scale)")
-        assert e <= 1e-2 * max(1.0, rs), (e, rs)
+        assert e <= 1e-2, (e, rs)
     finally:
         rdt1b.num_inference_timesteps = 5
 

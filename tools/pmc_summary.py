@@ -38,4 +38,8 @@ for cls in ("gemm_pp256", "gemm_ppk", "gemm_pw_", "gemm_pws", "gemm_glds", "attn
     print(f"CLASS {cls}: dispatches={n} bytes={tot:.0f} per_launch_bytes={tot/max(n,1):.0f}")
     out["gemm_pt_kv" if cls.startswith("gemm_pt_kernel") else cls.rstrip("_")] = {"dispatches": n, "per_launch_bytes": tot / max(n, 1)}
 if len(sys.argv) > 3:
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vla-touch_amd"))
+    from vlatouch import _lib
+    out["csrc_sha16"] = _lib.csrc_sha16()          # which kernel sources the counters were taken on (bench.py compares it with the tree it runs from)
     json.dump(out, open(sys.argv[3], "w"), indent=1)

@@ -10,6 +10,9 @@
 //   mode 2  `sc1` (agent-scope write-through) stores -> asm s_waitcnt vmcnt(0) -> flag ; consumer: poll -> acquire fence -> plain loads   (MI355X_MICROARCH "publish-large")
 //   mode 3  the same stores ; consumer: poll -> `sc0 sc1` loads, no acquire       mode 4: consumer `sc1` loads, no acquire
 //   mode 5 / 6 / 7 = 2 / 3 / 4 with `sc0 sc1` (system-scope) stores
+//   mode 8  SAME-XCD ONLY: plain stores (the lines stay dirty in the XCD's L2, which all 32 CUs of the XCD share) -> asm s_waitcnt vmcnt(0) -> flag ; consumer: poll ->
+//           `sc1` loads (bypass this CU's L1, served by the shared L2).  No write-back, no invalidate: valid only when producer and consumer sit on one XCD, so with the
+//           bands spread over the XCDs it MUST read stale words (the run shows how many) — a kernel using it has to derive band membership from HW_REG_XCC_ID
 // wait form  A  one counter per band (all 16 arrived before anything is read)        F  one flag per producer: member j's slab is read when flag j is up, in order j = 0 .. 15
 // placement  X  a band's 16 workgroups on ONE XCD (blockIdx % 8 = band % 8)           S  16 consecutive block ids = spread over all 8 XCDs
 // Every word read is checked against the value the seam's producer must have written (mode 1 / 2): `bad` must be 0.
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(256) void seam_kernel(uint16_t* __restrict__ buf0, 
       const int w = tid + 256 * i, row = w >> 4, c = w & 15, c8 = member * 16 + c;
       const uint4 v = word_of(s, band, row, c8);
       void* dst = bb + (long)row * COLS + c8 * 8;
-      if constexpr (MODE >= 5) st_wt<3>(dst, v); else if constexpr (MODE >= 2) st_wt<2>(dst, v); else *reinterpret_cast<uint4*>(dst) = v;
+      if constexpr (MODE >= 5 && MODE <= 7) st_wt<3>(dst, v); else if constexpr (MODE >= 2 && MODE <= 4) st_wt<2>(dst, v); else *reinterpret_cast<uint4*>(dst) = v;
     }
     if constexpr (MODE == 1) {
       __threadfence();                                   // release at agent scope (L2 write-back)
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(256) void seam_kernel(uint16_t* __restrict__ buf0, 
         const int w = tid + 256 * i, row = w >> 4, c8 = j * 16 + (w & 15);
         src[i] = bb + (long)row * COLS + c8 * 8;
       }
-      if constexpr (MODE == 3 || MODE == 6) ld10<3>(src, v); else if constexpr (MODE == 4 || MODE == 7) ld10<2>(src, v); else ld10<0>(src, v);
+      if constexpr (MODE == 3 || MODE == 6) ld10<3>(src, v); else if constexpr (MODE == 4 || MODE == 7 || MODE == 8) ld10<2>(src, v); else ld10<0>(src, v);
 #pragma unroll
       for (int i = 0; i < 10; ++i) {
         if (MODE != 0) {
@@ -204,6 +207,8 @@ int main() {
       run<4, true>("mode 4 sc1 st, sc1 ld, member flags", sx, b0, b1, flags, stamps, bad);
       run<5, true>("mode 5 sc0sc1 st, acquire, member fl", sx, b0, b1, flags, stamps, bad);
       run<7, true>("mode 7 sc0sc1 st, sc1 ld, member fl", sx, b0, b1, flags, stamps, bad);
+      run<8, false>("mode 8 plain st, sc1 ld, band cnt", sx, b0, b1, flags, stamps, bad);
+      run<8, true>("mode 8 plain st, sc1 ld, member fl", sx, b0, b1, flags, stamps, bad);
     }
     printf("\n");
   }

@@ -185,10 +185,12 @@ class RDTRunner:
                 dtype=self.compute_dtype, io_dtype=self.dtype, rms_mode=self.rms_mode, solver_state=self.solver_state, device=self.device)
             self._engine_key = key
             rg = self._range
-            if rg is not None and not rg.fell_back and self.compute_dtype == torch.float16 and not self._engine.weight_absmax <= 65504.0:
-                # static side of the guard: a weight of the bf16 checkpoint does not fit IEEE fp16 (it converted to inf)
+            if rg is not None and not rg.fell_back and self.compute_dtype == torch.float16 and not self._engine.fits_fp16:
+                # static side of the guard: a weight of the bf16 checkpoint does not fit IEEE fp16 (it converted to inf), or a q / k norm gain is so large that a
+                # normed q / k element could (8 |gain| > 65504)
                 import warnings
-                warnings.warn(f"RDTRunner: max |weight| = {self._engine.weight_absmax:g} does not fit IEEE fp16; computing in bf16", RuntimeWarning, stacklevel=3)
+                warnings.warn(f"RDTRunner: max |weight| = {self._engine.weight_absmax:g} / max q-k norm gain = {self._engine.headnorm_gain_absmax:g} does not fit IEEE fp16; "
+                              "computing in bf16", RuntimeWarning, stacklevel=3)
                 rg.fell_back = True
                 self._to_bf16()
         return self._engine

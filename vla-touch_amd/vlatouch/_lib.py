@@ -21,6 +21,19 @@ RANGE_XN_SAT, RANGE_NONFINITE, RANGE_GATE_SAT, RANGE_ATTN_EMPTY = 1, 2, 4, 8
 RANGE_NAMES = {RANGE_XN_SAT: "xn_saturated", RANGE_NONFINITE: "nonfinite", RANGE_GATE_SAT: "gate_saturated", RANGE_ATTN_EMPTY: "attention_row_empty"}
 
 
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources this tree's library is built from (csrc/*.hip, *.h, Makefile in name order): stamped into profiles/pmc_traffic.json by
+    tools/pmc_summary.py and compared by bench.py, so that a PMC figure taken on another build of the kernels is labelled as such."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(_HERE), "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def range_names(bits: int):
     return [n for b, n in RANGE_NAMES.items() if bits & b]
 

@@ -94,6 +94,10 @@ class RdtEngine(RangeGuard):
         # static side of the range guard: can the weights themselves be held in this 16-bit type?  (a bf16 checkpoint converted to IEEE fp16: |w| > 65504 became inf)
         mats = [t for t in W if t.dtype == dtype and t.dtype != torch.float32]
         self.weight_absmax = float(torch.stack([t.abs().max().float() for t in mats]).max()) if mats else 0.0
+        # the per-head q / k RMSNorm gains (weight order: csrc/vt_rdt.hip): a normed q / k element is at most 8 |gain| (mean-square form), stored in 16 bits
+        hn = [W[11 + 21 * i + j] for i in range(depth) for j in (3, 4, 12, 13)]
+        self.headnorm_gain_absmax = float(torch.stack([t.abs().max() for t in hn]).max())
+        self.fits_fp16 = self.weight_absmax <= 65504.0 and 8.0 * self.headnorm_gain_absmax <= 65504.0
         self._ws = _Workspace(dev)
         # frozen weights of the denoise-loop Linears, a second time in MFMA fragment order (csrc/vt_gemm_pw.hip streams them global -> VGPR)
         self._depth, self._rms_mode = depth, rms_mode
