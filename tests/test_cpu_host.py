@@ -275,3 +275,59 @@ def test_interpolant_schedule_tables_match_the_oracle():
     for name in ("gamma", "gamma_der", "gamma_inv", "epsilon"):
         with pytest.raises(NotImplementedError):
             getattr(si, name)(t)
+
+
+def test_auto_range_policy_first_call_synchronous_then_lagged(monkeypatch):
+    """vlatouch.engine.AutoRange (the compute_dtype="auto" policy, round 6) on a stand-in engine: the first call reads the guard synchronously, later calls through the
+    non-blocking read-out, nothing is read while a hipGraph is being captured, and a non-fp16 engine is never consulted."""
+    import warnings
+    from vlatouch import _lib
+    from vlatouch.engine import AutoRange
+
+    class Eng:
+        def __init__(self):
+            self.sync, self.poll, self.bits = 0, 0, 0
+
+        def overflowed(self, clear=False):
+            self.sync += 1
+            return self.bits
+
+        def range_poll(self):
+            self.poll += 1
+            return self.bits
+
+    capturing = {"on": False}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing["on"])
+    e, rg = Eng(), AutoRange("unit")
+    assert rg.after(e, is_f16=False) == 0 and (e.sync, e.poll) == (0, 0) and not rg.checked       # bf16 / fp32 engines: nothing to guard
+    capturing["on"] = True
+    assert rg.after(e, True) == 0 and (e.sync, e.poll) == (0, 0) and not rg.checked               # capture: no read, and the first real call still gets its check
+    capturing["on"] = False
+    assert rg.after(e, True) == 0 and (e.sync, e.poll) == (1, 0) and rg.checked
+    assert rg.after(e, True) == 0 and (e.sync, e.poll) == (1, 1)
+    e.bits = _lib.RANGE_XN_SAT | _lib.RANGE_NONFINITE
+    bits = rg.after(e, True)
+    assert bits == 3 and (e.sync, e.poll) == (1, 2)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rg.fall_back(bits)
+    assert rg.fell_back and rg.bits == 3 and len(w) == 1 and "xn_saturated, nonfinite" in str(w[0].message) and issubclass(w[0].category, RuntimeWarning)
+    assert _lib.range_names(8 | 4) == ["gate_saturated", "attention_row_empty"]
+
+
+def test_runner_compute_dtype_strings():
+    """RDTRunner(compute_dtype=...) accepts "auto" (default) / "f16" / "bf16" for a bf16 model, computes fp32 models in fp32, and rejects anything else (no GPU needed:
+    the engine is built lazily)."""
+    from models.rdt_runner import RDTRunner
+    cfg = {"rdt": {"hidden_size": 256, "depth": 1, "num_heads": 4, "rms_norm": "meansq"}, "lang_adaptor": "linear", "img_adaptor": "linear", "state_adaptor": "linear",
+           "noise_scheduler": {"num_train_timesteps": 1000, "num_inference_timesteps": 5, "beta_schedule": "squaredcos_cap_v2", "prediction_type": "sample"}}
+    kw = dict(action_dim=128, pred_horizon=8, config=cfg, lang_token_dim=32, img_token_dim=32, state_token_dim=128, max_lang_cond_len=8, img_cond_len=8, init_weights=False)
+    r = RDTRunner(dtype=torch.bfloat16, **kw)
+    assert r.compute_dtype == torch.float16 and r._range is not None
+    assert RDTRunner(dtype=torch.bfloat16, compute_dtype="f16", **kw)._range is None
+    rb = RDTRunner(dtype=torch.bfloat16, compute_dtype="bf16", **kw)
+    assert rb.compute_dtype == torch.bfloat16 and rb._range is None
+    rf = RDTRunner(dtype=torch.float32, **kw)
+    assert rf.compute_dtype == torch.float32 and rf._range is None
+    with pytest.raises(ValueError):
+        RDTRunner(dtype=torch.bfloat16, compute_dtype="fp8", **kw)
