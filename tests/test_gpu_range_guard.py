@@ -240,3 +240,48 @@ def test_dinov2_giant_swiglu_saturation_is_flagged_and_falls_back(monkeypatch):
         y = enc.forward(imgs)
     assert enc.engine.adt == L.BF16 and torch.equal(y, ybf[0])
     del y16
+
+
+def test_vit_towers_flag_a_non_finite_feature_and_fall_back():
+    """The GELU ViT towers in their fp16 storage mode: an fc1 bias of 2e5 in one channel makes the GELU output inf in fp16 -> fc2 -> NaN in the fp32 residual stream -> the
+    final norm's statistics are non-finite -> VT_RANGE_NONFINITE (csrc/vt_kernels.hip, rownorm kernels).  DINOv2Encoder / SiglipVisionTower in their default mode then
+    rebuild themselves with bf16 storage and return the bf16 engine's (finite) result."""
+    import types
+    from vlatouch import _lib as L, synth
+    from vlatouch.engine import DinoEngine
+    from residual_controller.visual_encoder import DINOv2Encoder
+    from models.multimodal_encoder.siglip_encoder import SiglipVisionTower
+    # ---- DINOv2-small
+    sd = {k: v.clone() for k, v in cases.dino_sd("small").items()}
+    sd["encoder.layer.3.mlp.fc1.bias"][7] = 2.0e5
+    imgs = torch.from_numpy(0.2 + 0.8 * synth.inputs_rng(5).random((2, 3, 224, 224), dtype=np.float32)).to("cuda:0")
+    e16 = DinoEngine(sd, heads=6, precision="fp16", device="cuda:0")
+    y16 = e16.forward([imgs], nhwc=False)
+    assert e16.overflowed() & L.RANGE_NONFINITE and not torch.isfinite(y16).all()
+    ebf = DinoEngine(sd, heads=6, precision="bf16", device="cuda:0")
+    ybf = ebf.forward([imgs], nhwc=False)
+    assert ebf.overflowed() == 0 and torch.isfinite(ybf).all()
+    enc = DINOv2Encoder("facebook/dinov2-small", device="cuda:0", precision="bf16", state_dict=sd)
+    assert enc.engine.adt == L.F16
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        y = enc.forward(imgs)
+    assert enc.engine.adt == L.BF16 and torch.equal(y, ybf[0])
+    # the benign weights keep fp16 and a clean word
+    enc0 = DINOv2Encoder("facebook/dinov2-small", device="cuda:0", precision="bf16", state_dict=cases.dino_sd("small"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        enc0.forward(imgs)
+        enc0.forward(imgs)
+    assert enc0.engine.adt == L.F16 and enc0.engine.overflowed() == 0
+    # ---- SigLIP tower (out_all: the final norm runs on every token)
+    c = synth.SIGLIP_CONFIGS["tiny"]
+    cfg = dict(hidden_size=c["hidden"], intermediate_size=c["inter"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"], image_size=c["image_size"], patch_size=14)
+    ssd = {k: v.clone() for k, v in cases.siglip_sd("tiny").items()}
+    ssd["encoder.layers.0.mlp.fc1.bias"][3] = 2.0e5
+    px = cases.siglip_pixels(2, c["image_size"], seed=8).to("cuda:0")
+    args = types.SimpleNamespace(mm_vision_select_feature="patch")
+    tower = SiglipVisionTower("synthetic", args, device="cuda:0", precision="bf16", state_dict=ssd, config=cfg)
+    assert tower.engine.adt == L.F16
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        out = tower(px)
+    assert tower.engine.adt == L.BF16 and torch.isfinite(out.float()).all()
